@@ -1,0 +1,459 @@
+// Context, model/graph upload, workspace, profiling and the public C entry points.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "lsr_internal.h"
+
+int lsr_fail(lsr_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    return code;
+}
+
+int lsr_reserve(lsr_ctx* ctx, lsr_buffer* buf, size_t bytes, const char* what) {
+    if (bytes <= buf->bytes) return LSR_OK;
+    LSR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (buf->ptr) LSR_HIP_CHECK(ctx, hipFree(buf->ptr));
+    buf->ptr = nullptr;
+    buf->bytes = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&buf->ptr, want);
+    if (e != hipSuccess)
+        return lsr_fail(ctx, LSR_ERR_HIP, "hipMalloc(%zu bytes) for %s failed: %s", want, what,
+                        hipGetErrorString(e));
+    buf->bytes = want;
+    return LSR_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------
+static hipEvent_t take_event(lsr_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void lsr_prof_begin(lsr_ctx* ctx, int kernel) {
+    if (!ctx->profiling) return;
+    lsr_ctx::pending p;
+    p.kernel = kernel;
+    p.start = take_event(ctx);
+    p.stop = take_event(ctx);
+    if (!p.start || !p.stop) return;
+    (void)hipEventRecord(p.start, ctx->stream);
+    ctx->pend.push_back(p);
+}
+
+void lsr_prof_end(lsr_ctx* ctx) {
+    if (!ctx->profiling || ctx->pend.empty()) return;
+    (void)hipEventRecord(ctx->pend.back().stop, ctx->stream);
+}
+
+static void drain_profile(lsr_ctx* ctx) {
+    for (auto& p : ctx->pend) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            ctx->prof_ms[p.kernel] += ms;
+            ctx->prof_n[p.kernel] += 1;
+        }
+        ctx->event_pool.push_back(p.start);
+        ctx->event_pool.push_back(p.stop);
+    }
+    ctx->pend.clear();
+}
+
+extern "C" int lsr_profile_enable(lsr_ctx* ctx, int on) {
+    if (!ctx) return LSR_ERR_ARG;
+    ctx->profiling = on != 0;
+    return LSR_OK;
+}
+
+extern "C" int lsr_profile_reset(lsr_ctx* ctx) {
+    if (!ctx) return LSR_ERR_ARG;
+    LSR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    drain_profile(ctx);
+    for (int k = 0; k < LSR_K_COUNT; ++k) {
+        ctx->prof_ms[k] = 0;
+        ctx->prof_n[k] = 0;
+    }
+    return LSR_OK;
+}
+
+extern "C" int lsr_profile_get(lsr_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches) {
+    if (!ctx || kernel_id < 0 || kernel_id >= LSR_K_COUNT) return LSR_ERR_ARG;
+    LSR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    drain_profile(ctx);
+    if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
+    if (launches) *launches = ctx->prof_n[kernel_id];
+    return LSR_OK;
+}
+
+// ---- host table builders --------------------------------------------------------------------
+extern "C" void lsr_host_hann_window(double* out) {
+    // scipy.signal.get_window("hann", 320, fftbins=True): 0.5 + 0.5*cos(linspace(-pi, pi, 321)[:-1])
+    const double step = (M_PI - (-M_PI)) / 320.0;
+    for (int i = 0; i < LSR_N_FFT; ++i) out[i] = 0.5 + 0.5 * cos((double)i * step + (-M_PI));
+}
+
+static double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3;
+    const double min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    if (f >= min_log_hz) return min_log_mel + log(f / min_log_hz) / logstep;
+    return f / f_sp;
+}
+
+static double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3;
+    const double min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    if (m >= min_log_mel) return min_log_hz * exp(logstep * (m - min_log_mel));
+    return f_sp * m;
+}
+
+extern "C" void lsr_host_mel_filterbank(float* out) {
+    // librosa.filters.mel(sr=16000, n_fft=320, n_mels=40, fmin=133.33, fmax=6855.4976,
+    // htk=False, norm="slaney"): triangles between consecutive mel points evaluated at the
+    // 50 Hz bin centres in float64, stored as float32, then scaled by 2/(f[i+2]-f[i]).
+    const int nm = LSR_N_MELS, nb = LSR_N_BINS;
+    double mel_f[LSR_N_MELS + 2];
+    const double lo = hz_to_mel(133.33), hi = hz_to_mel(6855.4976);
+    const double step = (hi - lo) / (nm + 1);
+    for (int i = 0; i < nm + 2; ++i) mel_f[i] = mel_to_hz(i == nm + 1 ? hi : (double)i * step + lo);
+    for (int i = 0; i < nm; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int k = 0; k < nb; ++k) {
+            const double fk = 50.0 * k;
+            const double lower = -(mel_f[i] - fk) / fd0;
+            const double upper = (mel_f[i + 2] - fk) / fd1;
+            double w = lower < upper ? lower : upper;
+            if (!(w > 0)) w = 0;
+            const float w32 = (float)w;
+            out[i * nb + k] = (float)((double)w32 * enorm);
+        }
+    }
+}
+
+extern "C" void lsr_host_dct_matrix(double* out) {
+    // scipy.fftpack.dct(type=2, norm="ortho") rows 0..12 over 40 inputs
+    for (int k = 0; k < LSR_N_MFCC; ++k) {
+        const double scale = k == 0 ? sqrt(1.0 / LSR_N_MELS) : sqrt(2.0 / LSR_N_MELS);
+        for (int n = 0; n < LSR_N_MELS; ++n)
+            out[k * LSR_N_MELS + n] = scale * cos(M_PI * k * (2 * n + 1) / (2.0 * LSR_N_MELS));
+    }
+}
+
+// ---- context ----------------------------------------------------------------------------------
+template <typename T>
+static int upload(lsr_ctx* ctx, T** dst, const T* src, size_t n, const char* what) {
+    if (*dst) {
+        LSR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LSR_HIP_CHECK(ctx, hipFree(*dst));
+        *dst = nullptr;
+    }
+    hipError_t e = hipMalloc((void**)dst, n * sizeof(T));
+    if (e != hipSuccess)
+        return lsr_fail(ctx, LSR_ERR_HIP, "hipMalloc for %s failed: %s", what, hipGetErrorString(e));
+    LSR_HIP_CHECK(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return LSR_OK;
+}
+
+int lsr_frontend_init(lsr_ctx* ctx) {
+    std::vector<double> win(LSR_N_FFT), tw160(16 * 10 * 2), tw320(LSR_N_BINS * 2), dct(LSR_N_MFCC * LSR_N_MELS);
+    std::vector<float> melw(LSR_N_MELS * LSR_N_BINS);
+    std::vector<int> lo(LSR_N_MELS), hi(LSR_N_MELS);
+    lsr_host_hann_window(win.data());
+    lsr_host_mel_filterbank(melw.data());
+    lsr_host_dct_matrix(dct.data());
+    for (int n2 = 0; n2 < 16; ++n2)
+        for (int k1 = 0; k1 < 10; ++k1) {
+            const double ang = -2.0 * M_PI * (double)(n2 * k1) / 160.0;
+            tw160[(n2 * 10 + k1) * 2 + 0] = cos(ang);
+            tw160[(n2 * 10 + k1) * 2 + 1] = sin(ang);
+        }
+    for (int k = 0; k < LSR_N_BINS; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / 320.0;
+        tw320[k * 2 + 0] = cos(ang);
+        tw320[k * 2 + 1] = sin(ang);
+    }
+    for (int b = 0; b < LSR_N_MELS; ++b) {
+        int first = LSR_N_BINS, last = 0;
+        for (int k = 0; k < LSR_N_BINS; ++k)
+            if (melw[b * LSR_N_BINS + k] != 0.f) {
+                if (k < first) first = k;
+                last = k + 1;
+            }
+        if (first > last) first = last = 0;
+        lo[b] = first;
+        hi[b] = last;
+    }
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_window, win.data(), win.size(), "window"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_tw160, tw160.data(), tw160.size(), "twiddles"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_tw320, tw320.data(), tw320.size(), "twiddles"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_melw, melw.data(), melw.size(), "mel weights"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_mel_lo, lo.data(), lo.size(), "mel ranges"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_mel_hi, hi.data(), hi.size(), "mel ranges"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_dct, dct.data(), dct.size(), "dct matrix"))) return rc;
+    return LSR_OK;
+}
+
+static void free_ptr(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+void lsr_frontend_free(lsr_ctx* ctx) {
+    free_ptr(ctx->d_window);
+    free_ptr(ctx->d_tw160);
+    free_ptr(ctx->d_tw320);
+    free_ptr(ctx->d_melw);
+    free_ptr(ctx->d_mel_lo);
+    free_ptr(ctx->d_mel_hi);
+    free_ptr(ctx->d_dct);
+}
+
+extern "C" int lsr_ctx_create(int device, lsr_ctx** out) {
+    if (!out) return LSR_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return LSR_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return LSR_ERR_HIP;
+    lsr_ctx* ctx = new lsr_ctx();
+    ctx->device = device;
+    int rc = lsr_frontend_init(ctx);
+    if (rc != LSR_OK) {
+        fprintf(stderr, "lsr_ctx_create: %s\n", ctx->error.c_str());
+        lsr_frontend_free(ctx);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return LSR_OK;
+}
+
+extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
+    if (!ctx) return LSR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    lsr_frontend_free(ctx);
+    free_ptr(ctx->d_wfrag);
+    free_ptr(ctx->d_mean);
+    free_ptr(ctx->d_lognorm);
+    free_ptr(ctx->d_band);
+    free_ptr(ctx->d_flags);
+    free_ptr(ctx->d_word_of);
+    free_ptr(ctx->d_lower_of);
+    free_ptr(ctx->d_upper_of);
+    lsr_buffer* bufs[] = {&ctx->ws_frame_utt, &ctx->ws_mel, &ctx->ws_uttmax, &ctx->ws_feats,
+                          &ctx->ws_ll, &ctx->ws_tracer, &ctx->ws_slab};
+    for (lsr_buffer* b : bufs) free_ptr(b->ptr);
+    for (auto& p : ctx->pend) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    delete ctx;
+    return LSR_OK;
+}
+
+extern "C" const char* lsr_last_error(const lsr_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+extern "C" int lsr_set_stream(lsr_ctx* ctx, void* hip_stream) {
+    if (!ctx) return LSR_ERR_ARG;
+    ctx->stream = (hipStream_t)hip_stream;
+    return LSR_OK;
+}
+
+extern "C" int lsr_synchronize(lsr_ctx* ctx) {
+    if (!ctx) return LSR_ERR_ARG;
+    LSR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return LSR_OK;
+}
+
+// ---- model ---------------------------------------------------------------------------------------
+extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, const double* whiten,
+                                const double* log_norm) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (n_states < 1 || !mean || !whiten || !log_norm) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_model_upload: bad argument");
+    if (n_states > 4096) return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_model_upload: %d states > 4096", n_states);
+    const int D = LSR_DIM;
+    std::vector<double> frag((size_t)n_states * LSR_KSTEPS * LSR_JTILES * 64, 0.0);
+    std::vector<double> mu((size_t)n_states * LSR_KPAD, 0.0);
+    for (int s = 0; s < n_states; ++s) {
+        for (int k = 0; k < D; ++k) mu[(size_t)s * LSR_KPAD + k] = mean[(size_t)s * D + k];
+        for (int ks = 0; ks < LSR_KSTEPS; ++ks)
+            for (int a = 0; a < LSR_JTILES; ++a)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k = 4 * ks + (lane >> 4), j = 16 * a + (lane & 15);
+                    if (k < D && j < D)
+                        frag[(((size_t)s * LSR_KSTEPS + ks) * LSR_JTILES + a) * 64 + lane] =
+                            whiten[((size_t)s * D + k) * D + j];
+                }
+    }
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_wfrag, frag.data(), frag.size(), "whitening fragments"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_mean, mu.data(), mu.size(), "means"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_lognorm, log_norm, (size_t)n_states, "log normalisers"))) return rc;
+    ctx->n_states = n_states;
+    return LSR_OK;
+}
+
+extern "C" int lsr_loop_graph_upload(lsr_ctx* ctx, int n_states, int n_words, const float* band,
+                                     const int32_t* word_lower, const int32_t* word_upper, int silence_word) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!band || !word_lower || !word_upper || n_words < 1 || n_states < 1)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_loop_graph_upload: bad argument");
+    if (n_states > LSR_MAX_STATES)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_loop_graph_upload: %d states > %d", n_states, LSR_MAX_STATES);
+    if (silence_word >= n_words) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_loop_graph_upload: silence_word out of range");
+    std::vector<float> b(3 * 64, -INFINITY);
+    std::vector<uint8_t> flags(64, 0), word_of(64, 0), lower_of(64, 0), upper_of(64, 0);
+    int expect = 0;
+    for (int w = 0; w < n_words; ++w) {
+        if (word_lower[w] != expect || word_upper[w] < word_lower[w] || word_upper[w] >= n_states)
+            return lsr_fail(ctx, LSR_ERR_ARG, "lsr_loop_graph_upload: words must tile the states in order");
+        for (int s = word_lower[w]; s <= word_upper[w]; ++s) {
+            word_of[s] = (uint8_t)w;
+            lower_of[s] = (uint8_t)word_lower[w];
+            upper_of[s] = (uint8_t)word_upper[w];
+        }
+        flags[word_lower[w]] |= 1;
+        flags[word_upper[w]] |= 2;
+        expect = word_upper[w] + 1;
+    }
+    if (expect != n_states) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_loop_graph_upload: words do not cover all states");
+    for (int d = 0; d < 3; ++d)
+        for (int s = 0; s < n_states; ++s) {
+            const float v = band[d * n_states + s];
+            if (v != v) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_loop_graph_upload: NaN transition");
+            b[d * 64 + s] = v;
+        }
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_band, b.data(), b.size(), "band"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_flags, flags.data(), flags.size(), "flags"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_word_of, word_of.data(), word_of.size(), "word map"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_lower_of, lower_of.data(), lower_of.size(), "word map"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_upper_of, upper_of.data(), upper_of.size(), "word map"))) return rc;
+    ctx->g_states = n_states;
+    ctx->g_words = n_words;
+    ctx->g_silence = silence_word;
+    return LSR_OK;
+}
+
+extern "C" int lsr_loop_set_between(lsr_ctx* ctx, double between, int between_is_f64) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (between != between) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_loop_set_between: NaN");
+    ctx->between = between;
+    ctx->between_is_f64 = between_is_f64 != 0;
+    return LSR_OK;
+}
+
+// ---- compute entry points ------------------------------------------------------------------------
+static int check_batch(lsr_ctx* ctx, const char* fn, int n_utts, int64_t total_frames) {
+    if (n_utts < 1 || total_frames < n_utts) return lsr_fail(ctx, LSR_ERR_ARG, "%s: empty batch", fn);
+    if (total_frames > ((int64_t)1 << 31) - 64)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "%s: %lld frames > 2^31", fn, (long long)total_frames);
+    return LSR_OK;
+}
+
+extern "C" int lsr_mfcc_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+                              const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!audio_d || !sample_off_d || !frame_off_d || !feats_d) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_mfcc_batch: null pointer");
+    int rc = check_batch(ctx, "lsr_mfcc_batch", n_utts, total_frames);
+    if (rc) return rc;
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return lsr_launch_mfcc(ctx, audio_d, sample_off_d, frame_off_d, n_utts, total_frames, feats_d);
+}
+
+extern "C" int lsr_emission_batch(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!feats_d || !ll_d) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_emission_batch: null pointer");
+    if (ctx->n_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_emission_batch: no model uploaded");
+    if (ctx->n_states > LSR_LL_STRIDE)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_emission_batch: %d states > %d", ctx->n_states, LSR_LL_STRIDE);
+    int rc = check_batch(ctx, "lsr_emission_batch", 1, total_frames);
+    if (rc) return rc;
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return lsr_launch_emission(ctx, feats_d, total_frames, ll_d);
+}
+
+static size_t ll_bytes(int64_t total_frames) {
+    return (size_t)((total_frames + 63) / 64 * 64) * LSR_LL_STRIDE * sizeof(float);
+}
+
+extern "C" int lsr_decode_loop_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d, int n_utts,
+                                     int64_t total_frames, int max_frames, float* scores_d, int8_t* paths_d,
+                                     uint8_t* labels_d, int32_t* n_labels_d, int label_cap) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!feats_d || !frame_off_d) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_batch: null pointer");
+    if (ctx->n_states == 0 || ctx->g_states == 0)
+        return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_loop_batch: model and loop graph must be uploaded first");
+    if (ctx->n_states != ctx->g_states)
+        return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_loop_batch: model has %d states, graph %d", ctx->n_states, ctx->g_states);
+    if (labels_d && label_cap < 1) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_batch: label_cap < 1");
+    int rc = check_batch(ctx, "lsr_decode_loop_batch", n_utts, total_frames);
+    if (rc) return rc;
+    if (max_frames < 1) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_batch: max_frames < 1");
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(total_frames), "emission scores"))) return rc;
+    if ((rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr))) return rc;
+    return lsr_launch_viterbi_loop(ctx, (const float*)ctx->ws_ll.ptr, frame_off_d, n_utts, total_frames, max_frames,
+                                   scores_d, paths_d, labels_d, n_labels_d, label_cap);
+}
+
+extern "C" int lsr_recognize_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+                                   const int64_t* frame_off_d, int n_utts, int64_t total_frames, int max_frames,
+                                   float* scores_d, int8_t* paths_d, uint8_t* labels_d, int32_t* n_labels_d,
+                                   int label_cap) {
+    if (!ctx) return LSR_ERR_ARG;
+    int rc = check_batch(ctx, "lsr_recognize_batch", n_utts, total_frames);
+    if (rc) return rc;
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if ((rc = lsr_reserve(ctx, &ctx->ws_feats, (size_t)total_frames * LSR_DIM * sizeof(float), "features"))) return rc;
+    if ((rc = lsr_mfcc_batch(ctx, audio_d, sample_off_d, frame_off_d, n_utts, total_frames, (float*)ctx->ws_feats.ptr)))
+        return rc;
+    return lsr_decode_loop_batch(ctx, (const float*)ctx->ws_feats.ptr, frame_off_d, n_utts, total_frames, max_frames,
+                                 scores_d, paths_d, labels_d, n_labels_d, label_cap);
+}
+
+extern "C" int lsr_decode_chain_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d, int n_utts,
+                                      int64_t total_frames, int max_frames, const int64_t* chain_off_d,
+                                      int64_t total_chain, const int32_t* chain_state_d, const float* chain_band_d,
+                                      const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d, float* final_d) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!feats_d || !frame_off_d || !chain_off_d || !chain_state_d || !chain_band_d || !chain_start_d)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_chain_batch: null pointer");
+    if (ctx->n_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_chain_batch: no model uploaded");
+    if (ctx->n_states > LSR_LL_STRIDE)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_decode_chain_batch: %d model states > %d", ctx->n_states, LSR_LL_STRIDE);
+    int rc = check_batch(ctx, "lsr_decode_chain_batch", n_utts, total_frames);
+    if (rc) return rc;
+    if (max_frames < 1 || total_chain < n_utts) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_chain_batch: bad sizes");
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(total_frames), "emission scores"))) return rc;
+    if ((rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr))) return rc;
+    return lsr_launch_viterbi_chain(ctx, (const float*)ctx->ws_ll.ptr, frame_off_d, n_utts, total_frames, max_frames,
+                                    chain_off_d, total_chain, chain_state_d, chain_band_d, chain_start_d, scores_d,
+                                    paths_d, final_d);
+}
+
+extern "C" int lsr_accumulate_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, int64_t total_frames,
+                                    int n_slots, double* count_d, double* sum_x_d, double* sum_xx_d) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!feats_d || !slot_d || !count_d || !sum_x_d || !sum_xx_d)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_accumulate_stats: null pointer");
+    if (n_slots < 1 || n_slots > 4096) return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_accumulate_stats: n_slots out of range");
+    int rc = check_batch(ctx, "lsr_accumulate_stats", 1, total_frames);
+    if (rc) return rc;
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return lsr_launch_stats(ctx, feats_d, slot_d, total_frames, n_slots, count_d, sum_x_d, sum_xx_d);
+}

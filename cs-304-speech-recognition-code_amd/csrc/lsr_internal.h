@@ -1,0 +1,99 @@
+// Internal declarations shared by the translation units of liblsr_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "lsr_hip.h"
+
+#define LSR_KPAD 40          // feature dimension padded to a multiple of the MFMA k-step (4)
+#define LSR_JTILES 3         // whitened components padded to 3 tiles of 16
+#define LSR_KSTEPS 10        // LSR_KPAD / 4
+
+struct lsr_buffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct lsr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    // front-end tables (device)
+    double* d_window = nullptr;      // [320]
+    double* d_tw160 = nullptr;       // [16][10][2]  W160^(n2*k1)
+    double* d_tw320 = nullptr;       // [161][2]     W320^k
+    float* d_melw = nullptr;         // [40][161]
+    int* d_mel_lo = nullptr;         // [40] first non-zero bin
+    int* d_mel_hi = nullptr;         // [40] one past the last non-zero bin
+    double* d_dct = nullptr;         // [13][40]
+
+    // model (device)
+    int n_states = 0;
+    double* d_wfrag = nullptr;       // [S][10][3][64]  MFMA A-operand fragments of U^T
+    double* d_mean = nullptr;        // [S][40]
+    double* d_lognorm = nullptr;     // [S]
+
+    // loop graph (device)
+    int g_states = 0, g_words = 0, g_silence = -1;
+    float* d_band = nullptr;         // [3][64]
+    uint8_t* d_flags = nullptr;      // [64] bit0 = word entry state, bit1 = word exit state
+    uint8_t* d_word_of = nullptr;    // [64] word index of each state
+    uint8_t* d_lower_of = nullptr;   // [64] first state of the state's word
+    uint8_t* d_upper_of = nullptr;   // [64] last state of the state's word
+    double between = -5.298317366548036;   // log(0.005)
+    int between_is_f64 = 1;
+
+    // workspace
+    lsr_buffer ws_frame_utt, ws_mel, ws_uttmax, ws_feats, ws_ll, ws_tracer, ws_slab;
+
+    // profiling
+    bool profiling = false;
+    struct pending { int kernel; hipEvent_t start, stop; };
+    std::vector<pending> pend;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[LSR_K_COUNT] = {0};
+    int64_t prof_n[LSR_K_COUNT] = {0};
+};
+
+int lsr_fail(lsr_ctx* ctx, int code, const char* fmt, ...);
+int lsr_reserve(lsr_ctx* ctx, lsr_buffer* buf, size_t bytes, const char* what);
+void lsr_prof_begin(lsr_ctx* ctx, int kernel);
+void lsr_prof_end(lsr_ctx* ctx);
+int lsr_frontend_init(lsr_ctx* ctx);
+void lsr_frontend_free(lsr_ctx* ctx);
+
+#define LSR_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return lsr_fail((ctx), LSR_ERR_HIP, "%s failed: %s (%s:%d)", #expr,               \
+                            hipGetErrorString(_e), __FILE__, __LINE__);                       \
+    } while (0)
+
+#define LSR_LAUNCH_CHECK(ctx, name)                                                           \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess)                                                                 \
+            return lsr_fail((ctx), LSR_ERR_HIP, "launch of %s failed: %s", name,              \
+                            hipGetErrorString(_e));                                           \
+    } while (0)
+
+// launchers implemented in the kernel translation units
+int lsr_launch_mfcc(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+                    const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d);
+int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d);
+int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
+                            int64_t total_frames, int max_frames, float* scores_d, int8_t* paths_d,
+                            uint8_t* labels_d, int32_t* n_labels_d, int label_cap);
+int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
+                             int64_t total_frames, int max_frames, const int64_t* chain_off_d,
+                             int64_t total_chain, const int32_t* chain_state_d,
+                             const float* chain_band_d, const uint8_t* chain_start_d,
+                             float* scores_d, int8_t* paths_d, float* final_d);
+int lsr_launch_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, int64_t total_frames,
+                     int n_slots, double* count_d, double* sum_x_d, double* sum_xx_d);

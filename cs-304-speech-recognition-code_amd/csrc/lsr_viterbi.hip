@@ -1,0 +1,301 @@
+// Viterbi recursion, back-trace and label extraction: one wavefront per utterance, one lane per
+// state (at most 64 states).
+//
+// Recursion for state s at frame t (all float32 adds, first maximal candidate wins):
+//   interior / chain states: best = max_{d=2,1,0} band[d][s] + prev[s-d]
+//   word-entry states (loop graph): candidates are  between + prev[last state of word w]  for
+//     every word w in ascending order, then the self loop band[0][s] + prev[s]
+//   cur[s] = best + ll[t][state(s)]
+// Back-pointers go to a global int8 table [frame][64]; the back-trace reads it back in blocks
+// of 64 frames staged in LDS.  The returned path reproduces the reference convention: entry
+// T-1 repeats the predecessor chosen at the last frame, the terminal state itself is never
+// written.
+#include "lsr_internal.h"
+
+#define VIT_LOOP32 0
+#define VIT_LOOP64 1
+#define VIT_CHAIN 2
+#define VIT_PREFETCH 8
+
+struct vit_args {
+    const float* ll;
+    const int64_t* frame_off;
+    // loop graph
+    const float* band;
+    const uint8_t* flags;
+    const uint8_t* word_of;
+    const uint8_t* lower_of;
+    const uint8_t* upper_of;
+    int n_states;
+    int silence;
+    float between32;
+    double between64;
+    // per-utterance chains
+    const int64_t* chain_off;
+    int64_t total_chain;
+    const int32_t* chain_state;
+    const float* chain_band;
+    const uint8_t* chain_start;
+    // outputs
+    float* scores;
+    int8_t* paths;
+    uint8_t* labels;
+    int32_t* n_labels;
+    int label_cap;
+    float* final_ll;
+    int8_t* tracer;
+    int path_cap;      // bytes reserved for the path in LDS (multiple of 64)
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int8_t* pathbuf = (int8_t*)smem;
+    int8_t* trblk = (int8_t*)smem + A.path_cap;          // [64][64]
+
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int64_t off = A.frame_off[b];
+    const int T = (int)(A.frame_off[b + 1] - off);
+    if (T < 1) return;
+
+    // ---- per-lane graph constants -------------------------------------------------------------
+    int n, gid;
+    float a0, a1, a2;
+    bool is_start, is_entry = false, is_exit = false;
+    if (MODE == VIT_CHAIN) {
+        const int64_t c0 = A.chain_off[b];
+        int len = (int)(A.chain_off[b + 1] - c0);
+        n = len > 64 ? 64 : len;
+        const bool live = lane < n;
+        const int64_t i = c0 + (live ? lane : 0);
+        gid = live ? A.chain_state[i] : 0;
+        a0 = live ? A.chain_band[i] : -INFINITY;
+        a1 = live ? A.chain_band[A.total_chain + i] : -INFINITY;
+        a2 = live ? A.chain_band[2 * A.total_chain + i] : -INFINITY;
+        is_start = live && A.chain_start[i] != 0;
+    } else {
+        n = A.n_states;
+        const bool live = lane < n;
+        gid = live ? lane : 0;
+        a0 = A.band[lane];
+        a1 = A.band[64 + lane];
+        a2 = A.band[128 + lane];
+        const unsigned f = A.flags[lane];
+        is_entry = live && (f & 1);
+        is_exit = live && (f & 2);
+        is_start = is_entry;
+    }
+    if (lane < 1) a1 = -INFINITY;
+    if (lane < 2) a2 = -INFINITY;
+
+    const float* llrow = A.ll + off * LSR_LL_STRIDE + gid;
+    int8_t* trrow = A.tracer + off * 64 + lane;
+
+    // frame 0: start states get emission + self-loop term
+    float prev = is_start ? llrow[0] + a0 : -INFINITY;
+
+    // ---- recursion -----------------------------------------------------------------------------
+    float ebuf[VIT_PREFETCH];
+#pragma unroll
+    for (int i = 0; i < VIT_PREFETCH; ++i) ebuf[i] = (1 + i < T) ? llrow[(int64_t)(1 + i) * LSR_LL_STRIDE] : 0.f;
+
+    for (int t0 = 1; t0 < T; t0 += VIT_PREFETCH) {
+#pragma unroll
+        for (int i = 0; i < VIT_PREFETCH; ++i) {
+            const int t = t0 + i;
+            if (t < T) {
+                const float e = ebuf[i];
+                if (t + VIT_PREFETCH < T) ebuf[i] = llrow[(int64_t)(t + VIT_PREFETCH) * LSR_LL_STRIDE];
+                const float p1 = __shfl_up(prev, 1);
+                const float p2 = __shfl_up(prev, 2);
+                const float v0 = a0 + prev, v1 = a1 + p1, v2 = a2 + p2;
+                float best = fmaxf(fmaxf(v2, v1), v0);
+                int ptr = (v2 == best) ? lane - 2 : ((v1 == best) ? lane - 1 : lane);
+                if (best == -INFINITY) ptr = 0;
+                float cur;
+                if (MODE == VIT_LOOP32) {
+                    const float cand = is_exit ? A.between32 + prev : -INFINITY;
+                    const float m = wave_max(cand);
+                    const unsigned long long mask = __ballot(is_exit && cand == m);
+                    const int first = __ffsll((long long)mask) - 1;
+                    if (is_entry) {
+                        const bool cross = m >= v0;
+                        best = cross ? m : v0;
+                        ptr = cross ? first : lane;
+                    }
+                    cur = best + e;
+                } else if (MODE == VIT_LOOP64) {
+                    const double cand = is_exit ? A.between64 + (double)prev : -(double)INFINITY;
+                    const double m = wave_max(cand);
+                    const unsigned long long mask = __ballot(is_exit && cand == m);
+                    const int first = __ffsll((long long)mask) - 1;
+                    double bestd = (double)best;
+                    if (is_entry) {
+                        const bool cross = m >= (double)v0;
+                        bestd = cross ? m : (double)v0;
+                        ptr = cross ? first : lane;
+                    }
+                    cur = (float)(bestd + (double)e);
+                } else {
+                    cur = best + e;
+                }
+                trrow[(int64_t)t * 64] = (int8_t)ptr;
+                prev = cur;
+            }
+        }
+    }
+
+    // ---- termination ---------------------------------------------------------------------------
+    int term;
+    float score;
+    if (MODE == VIT_CHAIN) {
+        term = n - 1;
+        score = __shfl(prev, term);
+        if (A.final_ll) A.final_ll[(int64_t)b * 64 + lane] = prev;
+    } else {
+        const float ends = is_exit ? prev : -INFINITY;
+        score = wave_max(ends);
+        const unsigned long long mask = __ballot(is_exit && ends == score);
+        term = __ffsll((long long)mask) - 1;
+        if (term < 0) term = 0;
+    }
+    if (A.scores && lane == 0) A.scores[b] = score;
+    if (!A.paths && !A.labels && !A.n_labels) return;
+
+    // ---- back-trace ----------------------------------------------------------------------------
+    __syncthreads();      // back-pointer stores of this wave are complete and visible to it
+    int cur = -1;
+    for (int blk = (T - 1) >> 6; blk >= 0; --blk) {
+        const int base = blk << 6;
+        if (base + lane < T && base + lane >= 1) {
+            const uint4* src = (const uint4*)(A.tracer + (off + base + lane) * 64);
+            uint4* dst = (uint4*)(trblk + lane * 64);
+            dst[0] = src[0];
+            dst[1] = src[1];
+            dst[2] = src[2];
+            dst[3] = src[3];
+        }
+        __syncthreads();
+        const int top = (base + 63 < T - 1) ? base + 63 : T - 1;
+        for (int t = top; t >= base; --t) {
+            if (t == T - 1) {
+                cur = (T > 1) ? (int)trblk[(t - base) * 64 + term] : -1;
+                if (lane == 0) pathbuf[t] = (int8_t)cur;
+            } else {
+                if (lane == 0) pathbuf[t] = (int8_t)cur;
+                if (t > 0) cur = (int)trblk[(t - base) * 64 + cur];
+            }
+        }
+        __syncthreads();
+    }
+    if (A.paths)
+        for (int t = lane; t < T; t += 64) A.paths[off + t] = pathbuf[t];
+
+    // ---- path -> word labels (loop graph only) ---------------------------------------------------
+    if (MODE != VIT_CHAIN && (A.labels || A.n_labels)) {
+        int count = 0;
+        for (int base = 0; base < T; base += 64) {
+            const int t = base + lane;
+            bool emit = false;
+            int w = 0;
+            if (t < T) {
+                const int p = pathbuf[t];
+                if (p >= 0) {
+                    w = A.word_of[p];
+                    if (t == 0) {
+                        emit = true;
+                    } else {
+                        const int q = pathbuf[t - 1];
+                        if (q >= 0 && p != q) {
+                            const int wq = A.word_of[q];
+                            emit = (w != wq) || (q == A.upper_of[q] && p == A.lower_of[q]);
+                        }
+                    }
+                    if (w == A.silence) emit = false;
+                }
+            }
+            const unsigned long long mask = __ballot(emit);
+            if (emit && A.labels) {
+                const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < A.label_cap) A.labels[(int64_t)b * A.label_cap + pos] = (uint8_t)w;
+            }
+            count += __popcll(mask);
+        }
+        if (A.n_labels && lane == 0) A.n_labels[b] = count;
+    }
+}
+
+static int launch(lsr_ctx* ctx, int mode, vit_args& A, int n_utts, int64_t total_frames, int max_frames) {
+    int rc = lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * 64, "back-pointers");
+    if (rc) return rc;
+    A.tracer = (int8_t*)ctx->ws_tracer.ptr;
+    A.path_cap = (max_frames + 63) / 64 * 64;
+    const size_t lds = (size_t)A.path_cap + 64 * 64;
+    if (lds > 160 * 1024)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "utterance of %d frames exceeds the %d-frame limit of the decoder", max_frames,
+                        160 * 1024 - 64 * 64 - 64);
+    void (*kern)(vit_args) = mode == VIT_LOOP32 ? lsr_viterbi_kernel<VIT_LOOP32>
+                             : mode == VIT_LOOP64 ? lsr_viterbi_kernel<VIT_LOOP64>
+                                                  : lsr_viterbi_kernel<VIT_CHAIN>;
+    if (lds > 64 * 1024)
+        LSR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lsr_prof_begin(ctx, LSR_K_VITERBI);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_utts), dim3(64), lds, ctx->stream, A);
+    lsr_prof_end(ctx);
+    LSR_LAUNCH_CHECK(ctx, "lsr_viterbi_kernel");
+    return LSR_OK;
+}
+
+int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
+                            int64_t total_frames, int max_frames, float* scores_d, int8_t* paths_d, uint8_t* labels_d,
+                            int32_t* n_labels_d, int label_cap) {
+    vit_args A = {};
+    A.ll = ll_d;
+    A.frame_off = frame_off_d;
+    A.band = ctx->d_band;
+    A.flags = ctx->d_flags;
+    A.word_of = ctx->d_word_of;
+    A.lower_of = ctx->d_lower_of;
+    A.upper_of = ctx->d_upper_of;
+    A.n_states = ctx->g_states;
+    A.silence = ctx->g_silence;
+    A.between32 = (float)ctx->between;
+    A.between64 = ctx->between;
+    A.scores = scores_d;
+    A.paths = paths_d;
+    A.labels = labels_d;
+    A.n_labels = n_labels_d;
+    A.label_cap = label_cap;
+    return launch(ctx, ctx->between_is_f64 ? VIT_LOOP64 : VIT_LOOP32, A, n_utts, total_frames, max_frames);
+}
+
+int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
+                             int64_t total_frames, int max_frames, const int64_t* chain_off_d, int64_t total_chain,
+                             const int32_t* chain_state_d, const float* chain_band_d, const uint8_t* chain_start_d,
+                             float* scores_d, int8_t* paths_d, float* final_d) {
+    vit_args A = {};
+    A.ll = ll_d;
+    A.frame_off = frame_off_d;
+    A.chain_off = chain_off_d;
+    A.total_chain = total_chain;
+    A.chain_state = chain_state_d;
+    A.chain_band = chain_band_d;
+    A.chain_start = chain_start_d;
+    A.scores = scores_d;
+    A.paths = paths_d;
+    A.final_ll = final_d;
+    return launch(ctx, VIT_CHAIN, A, n_utts, total_frames, max_frames);
+}

@@ -1,0 +1,359 @@
+"""ctypes binding of liblsr_hip.so (the C ABI declared in include/lsr_hip.h) and the
+per-process device engine the drop-in classes call.
+
+The HIP library is the only compute path: loading fails loudly when the shared object has not
+been built, and creating the engine fails loudly without a GPU.  PyTorch is used for device
+buffers, the stream handle and (in the distributed helpers) torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+DIM = 39
+MAX_STATES = 64
+LL_STRIDE = 64
+HOP = 160
+N_FFT = 320
+MIN_FRAMES = 9          # the width-9 delta filter needs 9 frames (librosa raises below that)
+KERNEL_IDS = {"frame_index": 0, "mel_power": 1, "mfcc_finish": 2, "emission": 3, "viterbi": 4, "stats": 5}
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "liblsr_hip.so"))
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def _declare(lib) -> None:
+    P = c_void_p
+    sig = {
+        "lsr_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+        "lsr_ctx_destroy": (c_int, [P]),
+        "lsr_last_error": (c_char_p, [P]),
+        "lsr_set_stream": (c_int, [P, P]),
+        "lsr_synchronize": (c_int, [P]),
+        "lsr_profile_enable": (c_int, [P, c_int]),
+        "lsr_profile_reset": (c_int, [P]),
+        "lsr_profile_get": (c_int, [P, c_int, POINTER(c_double), POINTER(c_int64)]),
+        "lsr_host_hann_window": (None, [POINTER(c_double)]),
+        "lsr_host_mel_filterbank": (None, [POINTER(c_float)]),
+        "lsr_host_dct_matrix": (None, [POINTER(c_double)]),
+        "lsr_model_upload": (c_int, [P, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+        "lsr_loop_graph_upload": (c_int, [P, c_int, c_int, POINTER(c_float), POINTER(c_int32), POINTER(c_int32), c_int]),
+        "lsr_loop_set_between": (c_int, [P, c_double, c_int]),
+        "lsr_mfcc_batch": (c_int, [P, P, P, P, c_int, c_int64, P]),
+        "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
+        "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
+        "lsr_recognize_batch": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
+        "lsr_decode_chain_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, c_int64, P, P, P, P, P, P]),
+        "lsr_accumulate_stats": (c_int, [P, P, P, c_int64, c_int, P, P, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+
+
+EXPORTED_SYMBOLS = [
+    "lsr_ctx_create", "lsr_ctx_destroy", "lsr_last_error", "lsr_set_stream", "lsr_synchronize",
+    "lsr_profile_enable", "lsr_profile_reset", "lsr_profile_get", "lsr_host_hann_window",
+    "lsr_host_mel_filterbank", "lsr_host_dct_matrix", "lsr_model_upload", "lsr_loop_graph_upload",
+    "lsr_loop_set_between", "lsr_mfcc_batch", "lsr_emission_batch", "lsr_decode_loop_batch",
+    "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats",
+]
+
+
+def load_library():
+    """Load liblsr_hip.so once.  No GPU is needed to load it (only to create a context)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(os.path.dirname(LIB_PATH))}` "
+                "(or __graft_entry__.build()).  There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def host_tables() -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(hann window f64[320], mel filterbank f32[40,161], DCT matrix f64[13,40]) as the kernels use them."""
+    lib = load_library()
+    win = np.empty(320, np.float64)
+    mel = np.empty((40, 161), np.float32)
+    dct = np.empty((13, 40), np.float64)
+    lib.lsr_host_hann_window(win.ctypes.data_as(POINTER(c_double)))
+    lib.lsr_host_mel_filterbank(mel.ctypes.data_as(POINTER(c_float)))
+    lib.lsr_host_dct_matrix(dct.ctypes.data_as(POINTER(c_double)))
+    return win, mel, dct
+
+
+def frames_of(n_samples: int) -> int:
+    return 1 + int(n_samples) // HOP
+
+
+class FeatureBatch:
+    """Ragged batch of (T_b, 39) feature matrices resident on the device."""
+
+    def __init__(self, feats, frame_off, lengths: np.ndarray):
+        self.feats = feats                    # torch float32 [total_frames, 39]
+        self.frame_off = frame_off            # torch int64 [B+1]
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        self.n = int(self.lengths.shape[0])
+        self.total_frames = int(self.lengths.sum())
+        self.max_frames = int(self.lengths.max())
+        self.host_off = np.concatenate([[0], np.cumsum(self.lengths)]).astype(np.int64)
+
+
+class AudioBatch:
+    """Ragged batch of 16 kHz clips resident on the device."""
+
+    def __init__(self, audio, sample_off, frame_off, n_samples: np.ndarray):
+        self.audio = audio
+        self.sample_off = sample_off
+        self.frame_off = frame_off
+        self.n_samples = np.asarray(n_samples, dtype=np.int64)
+        self.lengths = 1 + self.n_samples // HOP
+        self.n = int(self.n_samples.shape[0])
+        self.total_frames = int(self.lengths.sum())
+        self.max_frames = int(self.lengths.max())
+        self.host_off = np.concatenate([[0], np.cumsum(self.lengths)]).astype(np.int64)
+
+
+class Engine:
+    """One liblsr_hip context on one GPU plus the buffer plumbing around it."""
+
+    def __init__(self, device: Optional[int] = None):
+        import torch
+
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise NativeError("no GPU visible: liblsr_hip needs an AMD GPU (there is no CPU fallback)")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        self.device_index = device
+        torch.cuda.set_device(device)
+        self.device = torch.device("cuda", device)
+        ctx = c_void_p()
+        rc = self.lib.lsr_ctx_create(device, ctypes.byref(ctx))
+        if rc != 0 or not ctx.value:
+            raise NativeError(f"lsr_ctx_create({device}) failed with code {rc}")
+        self.ctx = ctx
+        self._check(self.lib.lsr_set_stream(self.ctx, c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self._model_token = None
+        self._graph_token = None
+        self._between = None
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            msg = self.lib.lsr_last_error(self.ctx)
+            raise NativeError(f"liblsr_hip error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None) is not None and self.ctx.value:
+            self.lib.lsr_ctx_destroy(self.ctx)
+            self.ctx = c_void_p()
+
+    def synchronize(self) -> None:
+        self._check(self.lib.lsr_synchronize(self.ctx))
+
+    @staticmethod
+    def _ptr(t) -> c_void_p:
+        return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+    def to_device(self, arr: np.ndarray):
+        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    # -- profiling --------------------------------------------------------------------------------
+    def profile_enable(self, on: bool) -> None:
+        self._check(self.lib.lsr_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_reset(self) -> None:
+        self._check(self.lib.lsr_profile_reset(self.ctx))
+
+    def profile_get(self, kernel: str) -> Tuple[float, int]:
+        ms, n = c_double(0), c_int64(0)
+        self._check(self.lib.lsr_profile_get(self.ctx, KERNEL_IDS[kernel], ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    # -- batches ----------------------------------------------------------------------------------
+    def audio_batch(self, signals: Sequence[np.ndarray]) -> AudioBatch:
+        if len(signals) == 0:
+            raise ValueError("empty batch")
+        n = np.array([s.shape[0] for s in signals], dtype=np.int64)
+        frames = 1 + n // HOP
+        if frames.min() < MIN_FRAMES:
+            raise ValueError(f"a clip yields {int(frames.min())} frames; the width-9 delta filter needs at least {MIN_FRAMES}")
+        flat = np.concatenate([np.asarray(s, dtype=np.float32) for s in signals])
+        soff = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        foff = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
+        return AudioBatch(self.to_device(flat), self.to_device(soff), self.to_device(foff), n)
+
+    def feature_batch(self, feats: Sequence[np.ndarray]) -> FeatureBatch:
+        if len(feats) == 0:
+            raise ValueError("empty batch")
+        lengths = np.array([f.shape[0] for f in feats], dtype=np.int64)
+        if lengths.min() < 1:
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+        for f in feats:
+            assert f.ndim == 2 and f.shape[1] == DIM
+        flat = np.concatenate([np.asarray(f, dtype=np.float32) for f in feats], axis=0)
+        foff = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        return FeatureBatch(self.to_device(flat), self.to_device(foff), lengths)
+
+    # -- front-end --------------------------------------------------------------------------------
+    def mfcc(self, batch: AudioBatch):
+        """float32 device tensor [total_frames, 39] (time-major)."""
+        out = self.empty((batch.total_frames, DIM), self.torch.float32)
+        self._check(self.lib.lsr_mfcc_batch(self.ctx, self._ptr(batch.audio), self._ptr(batch.sample_off),
+                                            self._ptr(batch.frame_off), batch.n, batch.total_frames, self._ptr(out)))
+        return FeatureBatch(out, batch.frame_off, batch.lengths)
+
+    # -- model / graph ----------------------------------------------------------------------------
+    def set_model(self, token, mean: np.ndarray, whiten: np.ndarray, log_norm: np.ndarray) -> None:
+        if token is not None and token == self._model_token:
+            return
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        whiten = np.ascontiguousarray(whiten, dtype=np.float64)
+        log_norm = np.ascontiguousarray(log_norm, dtype=np.float64)
+        S = mean.shape[0]
+        assert mean.shape == (S, DIM) and whiten.shape == (S, DIM, DIM) and log_norm.shape == (S,)
+        dp = POINTER(c_double)
+        self._check(self.lib.lsr_model_upload(self.ctx, S, mean.ctypes.data_as(dp), whiten.ctypes.data_as(dp),
+                                              log_norm.ctypes.data_as(dp)))
+        self._model_token = token
+        self.n_model_states = S
+
+    def set_loop_graph(self, token, band: np.ndarray, lower: Sequence[int], upper: Sequence[int], silence_word: int) -> None:
+        if token is not None and token == self._graph_token:
+            return
+        band = np.ascontiguousarray(band, dtype=np.float32)
+        lo = np.ascontiguousarray(lower, dtype=np.int32)
+        up = np.ascontiguousarray(upper, dtype=np.int32)
+        S = band.shape[1]
+        self._check(self.lib.lsr_loop_graph_upload(self.ctx, S, lo.shape[0], band.ctypes.data_as(POINTER(c_float)),
+                                                   lo.ctypes.data_as(POINTER(c_int32)), up.ctypes.data_as(POINTER(c_int32)),
+                                                   int(silence_word)))
+        self._graph_token = token
+
+    def set_between(self, between) -> None:
+        """Python ints/floats and float32 scalars add in float32; np.float64 adds in float64 (NumPy promotion)."""
+        wide = isinstance(between, np.float64)
+        key = (float(between), wide)
+        if key != self._between:
+            self._check(self.lib.lsr_loop_set_between(self.ctx, float(between), 1 if wide else 0))
+            self._between = key
+
+    # -- emission / decoding ----------------------------------------------------------------------
+    def emission(self, fb: FeatureBatch):
+        rows = (fb.total_frames + 63) // 64 * 64
+        out = self.empty((rows, LL_STRIDE), self.torch.float32)
+        self._check(self.lib.lsr_emission_batch(self.ctx, self._ptr(fb.feats), fb.total_frames, self._ptr(out)))
+        return out
+
+    def decode_loop(self, fb: FeatureBatch, want_paths: bool = False, label_cap: int = 32):
+        t = self.torch
+        scores = self.empty((fb.n,), t.float32)
+        paths = self.empty((fb.total_frames,), t.int8) if want_paths else None
+        labels = self.empty((fb.n, label_cap), t.uint8)
+        n_labels = self.empty((fb.n,), t.int32)
+        self._check(self.lib.lsr_decode_loop_batch(self.ctx, self._ptr(fb.feats), self._ptr(fb.frame_off), fb.n,
+                                                   fb.total_frames, fb.max_frames, self._ptr(scores), self._ptr(paths),
+                                                   self._ptr(labels), self._ptr(n_labels), label_cap))
+        return scores, paths, labels, n_labels
+
+    def recognize(self, ab: AudioBatch, want_paths: bool = False, label_cap: int = 32, out=None):
+        t = self.torch
+        if out is None:
+            out = (self.empty((ab.n,), t.float32), self.empty((ab.total_frames,), t.int8) if want_paths else None,
+                   self.empty((ab.n, label_cap), t.uint8), self.empty((ab.n,), t.int32))
+        scores, paths, labels, n_labels = out
+        self._check(self.lib.lsr_recognize_batch(self.ctx, self._ptr(ab.audio), self._ptr(ab.sample_off),
+                                                 self._ptr(ab.frame_off), ab.n, ab.total_frames, ab.max_frames,
+                                                 self._ptr(scores), self._ptr(paths), self._ptr(labels),
+                                                 self._ptr(n_labels), label_cap))
+        return out
+
+    def decode_chain(self, fb: FeatureBatch, chain_off: np.ndarray, chain_state: np.ndarray, chain_band: np.ndarray,
+                     chain_start: np.ndarray, want_paths: bool = True, want_final: bool = False):
+        t = self.torch
+        chain_off = np.ascontiguousarray(chain_off, dtype=np.int64)
+        total_chain = int(chain_off[-1])
+        lens = np.diff(chain_off)
+        if chain_off.shape[0] != fb.n + 1 or lens.min() < 1 or lens.max() > MAX_STATES:
+            raise ValueError(f"every chain needs 1..{MAX_STATES} states")
+        chain_state = np.ascontiguousarray(chain_state, dtype=np.int32)
+        if chain_state.shape != (total_chain,) or chain_state.min() < 0 or chain_state.max() >= self.n_model_states:
+            raise ValueError("chain_state out of range of the uploaded model")
+        chain_band = np.ascontiguousarray(chain_band, dtype=np.float32)
+        assert chain_band.shape == (3, total_chain)
+        if np.isnan(chain_band).any():
+            raise ValueError("NaN transition log-probability")
+        chain_start = np.ascontiguousarray(chain_start, dtype=np.uint8)
+        assert chain_start.shape == (total_chain,)
+        d_off, d_state = self.to_device(chain_off), self.to_device(chain_state)
+        d_band, d_start = self.to_device(chain_band), self.to_device(chain_start)
+        scores = self.empty((fb.n,), t.float32)
+        paths = self.empty((fb.total_frames,), t.int8) if want_paths else None
+        final = self.empty((fb.n, 64), t.float32) if want_final else None
+        self._check(self.lib.lsr_decode_chain_batch(self.ctx, self._ptr(fb.feats), self._ptr(fb.frame_off), fb.n,
+                                                    fb.total_frames, fb.max_frames, self._ptr(d_off), total_chain,
+                                                    self._ptr(d_state), self._ptr(d_band), self._ptr(d_start),
+                                                    self._ptr(scores), self._ptr(paths), self._ptr(final)))
+        self.synchronize()     # the chain arrays above must outlive the kernels
+        return scores, paths, final
+
+    def accumulate_stats(self, fb_feats, slots, total_frames: int, n_slots: int):
+        """(count f64[n], sum_x f64[n,39], sum_xx f64[n,39,39]) device tensors."""
+        t = self.torch
+        count = self.empty((n_slots,), t.float64)
+        sum_x = self.empty((n_slots, DIM), t.float64)
+        sum_xx = self.empty((n_slots, DIM, DIM), t.float64)
+        self._check(self.lib.lsr_accumulate_stats(self.ctx, self._ptr(fb_feats), self._ptr(slots), total_frames, n_slots,
+                                                  self._ptr(count), self._ptr(sum_x), self._ptr(sum_xx)))
+        return count, sum_x, sum_xx
+
+
+_engine: Optional[Engine] = None
+_engine_pid: Optional[int] = None
+
+
+def get_engine() -> Engine:
+    """Process-wide engine (created on first use; re-created in a forked/spawned child)."""
+    global _engine, _engine_pid
+    if _engine is None or _engine_pid != os.getpid():
+        _engine = Engine()
+        _engine_pid = os.getpid()
+    return _engine
+
+
+_token_counter = 0
+
+
+def new_token() -> Tuple[int, int]:
+    """Identity of a set of uploaded arrays; unique within and across processes."""
+    global _token_counter
+    _token_counter += 1
+    return (os.getpid(), _token_counter)
+
+
+def split_ragged(flat: np.ndarray, host_off: np.ndarray) -> List[np.ndarray]:
+    return [flat[host_off[i]:host_off[i + 1]] for i in range(host_off.shape[0] - 1)]

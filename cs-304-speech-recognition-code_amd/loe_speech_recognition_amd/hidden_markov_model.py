@@ -1,0 +1,690 @@
+"""Gaussian-HMM word models, decoders and trainers with the reference's interface
+(src/loe_speech_recognition/hidden_markov_model.py), backed by liblsr_hip.
+
+Every float computation of the hot path (emission scores, Viterbi recursions, label
+extraction, alignment statistics) runs on the GPU through the C ABI; this module holds the
+model bookkeeping, builds the flat arrays the device consumes and turns reduced statistics
+into new parameters.  Each class also offers batched entry points (``predict_batch`` ...)
+that replace the reference's ProcessPoolExecutor fan-out with one device call.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.linalg
+
+from . import _native
+from .model_boundary import ModelBoundary
+from .signal import Signal, SortedSignals
+from .transition_probability import LogTransitionProbabilities, TransitionProbabilities
+
+try:                                     # progress bars are optional
+    from tqdm import tqdm
+except Exception:                        # pragma: no cover
+    class tqdm:                          # type: ignore
+        def __init__(self, *a, **k): pass
+        def update(self, *a): pass
+        def close(self): pass
+
+logger = logging.getLogger(__name__)
+
+_LOG_2PI = float(np.log(2 * np.pi))
+MODEL_FILE = "model.npz"
+
+
+@dataclass
+class MultivariateNormal:
+    """Frozen full-covariance Gaussian (hidden_markov_model.py:20-48).  Holds what SciPy's frozen
+    multivariate_normal holds for ``allow_singular=False``: the float64 mean, the whitening
+    matrix U = V diag(lambda^-1/2) of the eigendecomposition and log|Sigma|."""
+    dim_of_features: int = field(init=False)
+    mean: np.ndarray = field(init=False)
+    whiten: np.ndarray = field(init=False)
+    log_pdet: float = field(init=False)
+
+    @classmethod
+    def from_means_covariances(cls, mean: np.ndarray, covariance: np.ndarray) -> "MultivariateNormal":
+        mn = cls()
+        mn.mean = np.asarray(mean, dtype=float)
+        cov = np.asarray(covariance, dtype=float)
+        lam, vec = scipy.linalg.eigh(cov, lower=True, check_finite=True)
+        eps = 1e6 * np.finfo("d").eps * np.max(abs(lam))
+        if np.min(lam) < -eps:
+            raise ValueError("The input matrix must be symmetric positive semidefinite.")
+        kept = lam[lam > eps]
+        if len(kept) < len(lam):
+            raise np.linalg.LinAlgError(
+                "When `allow_singular is False`, the input matrix must be symmetric positive definite.")
+        mn.whiten = np.multiply(vec, np.sqrt(1.0 / lam))
+        mn.log_pdet = float(np.sum(np.log(kept)))
+        mn.dim_of_features = mn.mean.shape[0]
+        return mn
+
+    @property
+    def log_norm(self) -> float:
+        return self.dim_of_features * _LOG_2PI + self.log_pdet
+
+    def log_pdf(self, x: np.ndarray) -> np.float32:
+        assert x.shape[0] == self.dim_of_features
+        eng = _native.get_engine()
+        eng.set_model(None, self.mean[None], self.whiten[None], np.array([self.log_norm]))
+        fb = eng.feature_batch([np.asarray(x, dtype=np.float32)[None, :]])
+        return eng.emission(fb)[0, 0].cpu().numpy()[()]
+
+
+def stack_gaussians(gaussians: Sequence[MultivariateNormal]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    mean = np.stack([g.mean for g in gaussians])
+    whiten = np.stack([g.whiten for g in gaussians])
+    log_norm = np.array([g.log_norm for g in gaussians], dtype=np.float64)
+    return mean, whiten, log_norm
+
+
+@dataclass
+class HiddenMarkovModel:
+    # Mains
+    label: str
+
+    # Settings
+    isMultiProcessing: bool = field(default=True)     # kept for interface compatibility: batching replaces the pool
+    isTqdm: bool = field(default=True)
+
+    # Internals
+    _multivariate_normals: List[MultivariateNormal] = field(default_factory=list)
+    _log_transition_probs: LogTransitionProbabilities = field(default_factory=LogTransitionProbabilities)
+
+    def __str__(self) -> str:
+        return self.label
+
+    @property
+    def num_of_states(self) -> int:
+        return len(self._multivariate_normals)
+
+    @property
+    def dim_of_features(self) -> int:
+        return self._multivariate_normals[0].dim_of_features
+
+    # -- device plumbing ---------------------------------------------------------------------------
+    def _device_model(self):
+        cache = self.__dict__.get("_dev_cache")
+        if cache is None or cache["n"] != len(self._multivariate_normals) or cache["src"] is not self._multivariate_normals:
+            cache = {"token": _native.new_token(), "n": len(self._multivariate_normals),
+                     "src": self._multivariate_normals, "arrays": stack_gaussians(self._multivariate_normals)}
+            self.__dict__["_dev_cache"] = cache
+        return cache["token"], cache["arrays"]
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_dev_cache", None)
+        return state
+
+    def _chain(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(state ids, band [3,N], start flags) of this model as one alignment chain."""
+        n = self.num_of_states
+        start = np.zeros(n, dtype=np.uint8)
+        start[0] = 1
+        return np.arange(n, dtype=np.int32), self._log_transition_probs.band(), start
+
+    # -- decoding ----------------------------------------------------------------------------------
+    def predict(self, signal: np.ndarray) -> Tuple[np.float32, np.ndarray]:
+        assert len(self._multivariate_normals) > 0
+        assert self.dim_of_features == signal.shape[1]
+        return self._viterbi(signal)
+
+    def _viterbi(self, observation_sequence: np.ndarray) -> Tuple[np.float32, np.ndarray]:
+        return self.predict_batch([observation_sequence])[0]
+
+    def predict_batch(self, signals, want_paths: bool = True) -> List[Tuple[np.float32, Optional[np.ndarray]]]:
+        """(score, int8 path) per utterance from one device call.  ``signals`` is a list of
+        (T, 39) arrays or a device-resident FeatureBatch."""
+        eng = _native.get_engine()
+        fb = signals if isinstance(signals, _native.FeatureBatch) else eng.feature_batch(signals)
+        token, arrays = self._device_model()
+        eng.set_model(token, *arrays)
+        ids, band, start = self._chain()
+        n = ids.shape[0]
+        off = np.arange(fb.n + 1, dtype=np.int64) * n
+        scores, paths, _ = eng.decode_chain(fb, off, np.tile(ids, fb.n), np.tile(band, (1, fb.n)),
+                                            np.tile(start, fb.n), want_paths=want_paths)
+        scores = scores.cpu().numpy()
+        plist = _native.split_ragged(paths.cpu().numpy(), fb.host_off) if want_paths else [None] * fb.n
+        return [(scores[i], plist[i]) for i in range(fb.n)]
+
+    # -- persistence (flat arrays instead of the reference's pickled SciPy objects) -----------------
+    def _arrays_to_save(self) -> Dict[str, np.ndarray]:
+        mean, whiten, _ = stack_gaussians(self._multivariate_normals)
+        return {"label": np.array(self.label), "mean": mean, "whiten": whiten,
+                "log_pdet": np.array([g.log_pdet for g in self._multivariate_normals]),
+                "log_trans": self._log_transition_probs.to_array()}
+
+    def save(self, parent_folder_path: str = "./cache") -> None:
+        folder = os.path.join(parent_folder_path, f"{self.label}")
+        os.makedirs(folder, exist_ok=True)
+        np.savez(os.path.join(folder, MODEL_FILE), **self._arrays_to_save())
+
+    @classmethod
+    def from_folder(cls, model_folder_path: str):
+        if not os.path.isdir(model_folder_path):
+            raise FileNotFoundError
+        model = cls(cls._model_folder_name_parser(model_folder_path))
+        with np.load(os.path.join(model_folder_path, MODEL_FILE), allow_pickle=False) as z:
+            model._load_arrays(z)
+        return model
+
+    def _load_arrays(self, z) -> None:
+        self._multivariate_normals = []
+        for mean, whiten, log_pdet in zip(z["mean"], z["whiten"], z["log_pdet"]):
+            g = MultivariateNormal()
+            g.mean, g.whiten, g.log_pdet, g.dim_of_features = mean, whiten, float(log_pdet), mean.shape[0]
+            self._multivariate_normals.append(g)
+        dense = z["log_trans"]
+        ltp = LogTransitionProbabilities(dense.shape[0])
+        for i in range(dense.shape[0]):
+            for j in range(dense.shape[1]):
+                if not np.isnan(dense[i, j]):
+                    ltp[(i, j)] = dense[i, j]
+        self._log_transition_probs = ltp
+
+    @staticmethod
+    def _model_folder_name_parser(folder_path: str) -> str:
+        return str(folder_path.split("/")[-1])
+
+
+def _stats_to_host(count, sum_x, sum_xx) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    return count.cpu().numpy(), sum_x.cpu().numpy(), sum_xx.cpu().numpy()
+
+
+@dataclass
+class HiddenMarkovModelTrainable(HiddenMarkovModel):
+
+    class HMMTrainMeanFail(Exception):
+        """A state received no frames (hidden_markov_model.py:214-217, 326-329)."""
+
+    class HMMTrainConverge(Exception):
+        """New means are np.allclose to the previous ones (hidden_markov_model.py:220-223, 333-335)."""
+
+    _means: np.ndarray = field(init=False)
+    _covariances: np.ndarray = field(init=False)
+    _transition_probs: TransitionProbabilities = field(init=False)
+
+    @property
+    def num_of_states(self) -> int:
+        return self._means.shape[0]
+
+    @classmethod
+    def from_data(cls, label: str, mfccs: List[np.ndarray], num_of_states: int = 5, max_iterations: int = 100,
+                  isMultiProcessingTraining: bool = True, isTqdm: bool = True):
+        """Segmental k-means for one word (hidden_markov_model.py:233-281).  The utterances are
+        uploaded once; every iteration is one batched alignment plus one statistics reduction."""
+        model = cls(label, isMultiProcessing=isMultiProcessingTraining, isTqdm=isTqdm)
+        model._means, model._covariances, model._transition_probs = model._init_parameters(mfccs[0], num_of_states)
+        model._update_inference_weights()
+        fb = _native.get_engine().feature_batch(mfccs)
+        bar = tqdm(desc=f"Train {model.label} model", total=max_iterations, position=1, disable=not model.isTqdm)
+        for _ in range(max_iterations):
+            try:
+                model._train(fb)
+                model._update_inference_weights()
+            except cls.HMMTrainMeanFail:
+                logger.error("Failed to train model")
+                raise
+            except cls.HMMTrainConverge:
+                break
+            bar.update()
+        bar.close()
+        model._update_inference_weights()
+        return model
+
+    def _update_inference_weights(self) -> None:
+        """hidden_markov_model.py:283-292."""
+        self._log_transition_probs = LogTransitionProbabilities.from_transition_probability(self._transition_probs)
+        self._multivariate_normals = self.get_multivariate_normals(self._means, self._covariances)
+
+    def _train(self, mfccs) -> None:
+        """One iteration (hidden_markov_model.py:294-318): align every utterance with the current
+        model, then re-estimate from the frames of each state."""
+        eng = _native.get_engine()
+        fb = mfccs if isinstance(mfccs, _native.FeatureBatch) else eng.feature_batch(mfccs)
+        token, arrays = self._device_model()
+        eng.set_model(token, *arrays)
+        ids, band, start = self._chain()
+        n = ids.shape[0]
+        off = np.arange(fb.n + 1, dtype=np.int64) * n
+        _, paths, _ = eng.decode_chain(fb, off, np.tile(ids, fb.n), np.tile(band, (1, fb.n)), np.tile(start, fb.n))
+        slots = paths.to(eng.torch.int32)            # a left-to-right path is non-decreasing: slot = state
+        count, sum_x, sum_xx = _stats_to_host(*eng.accumulate_stats(fb.feats, slots, fb.total_frames, n))
+        p = paths.cpu().numpy().astype(np.int64)
+        same_utt = np.ones(p.shape[0] - 1, dtype=bool)
+        same_utt[fb.host_off[1:-1] - 1] = False
+        trans = np.bincount(p[:-1][same_utt] * n + p[1:][same_utt], minlength=n * n).reshape(n, n)
+        self._m_step(count, sum_x, sum_xx, trans)
+
+    def _m_step(self, count: np.ndarray, sum_x: np.ndarray, sum_xx: np.ndarray, trans_counts: np.ndarray) -> None:
+        """hidden_markov_model.py:320-350 from reduced statistics: mean = sum_x / n,
+        cov = (sum_xx - n m m^T) / (n - 1) + 1e-3 I (np.cov's ddof = 1), transitions = counts / row sums."""
+        if np.any(count == 0):
+            raise self.HMMTrainMeanFail
+        mean64 = sum_x / count[:, None]
+        new_means = mean64.astype(np.float32)
+        if np.allclose(new_means, self._means):
+            raise self.HMMTrainConverge
+        self._means = new_means
+        d = self._covariances.shape[1]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for s in range(count.shape[0]):
+                cov = (sum_xx[s] - count[s] * np.outer(mean64[s], mean64[s])) / (count[s] - 1)
+                self._covariances[s] = (cov + np.eye(d) * 0.001).astype(np.float32)
+            probs = (trans_counts / np.sum(trans_counts, axis=1, keepdims=True)).astype(np.float32)
+        self._transition_probs = TransitionProbabilities.from_transition_probability(probs)
+
+    def _update_middleware_parameters(self, sorted_signals: SortedSignals) -> None:
+        """Same re-estimation from host-side aligned signals (hidden_markov_model.py:320-350);
+        the frames are uploaded and reduced on the device."""
+        n = self.num_of_states
+        frames: List[np.ndarray] = []
+        slots: List[np.ndarray] = []
+        for sig in sorted_signals._signals:
+            start = 0
+            slot = np.full(len(sig.path), -1, dtype=np.int32)
+            for state in range(n):                     # signal.py:23-47 walk
+                end = start
+                while end < len(sig.path) and sig.path[end] == state:
+                    end += 1
+                slot[start:end] = state
+                start = end
+            frames.append(np.asarray(sig.signal, dtype=np.float32))
+            slots.append(slot)
+        if not frames:
+            raise self.HMMTrainMeanFail
+        eng = _native.get_engine()
+        flat = np.concatenate(frames, axis=0)
+        count, sum_x, sum_xx = _stats_to_host(*eng.accumulate_stats(eng.to_device(flat), eng.to_device(np.concatenate(slots)),
+                                                                     flat.shape[0], n))
+        self._m_step(count, sum_x, sum_xx, sorted_signals.transition_counts)
+
+    def _train_external(self, signals: List[Signal]) -> None:
+        sorted_signals = SortedSignals(self.num_of_states)
+        for s in signals:
+            sorted_signals.append(s)
+        self._update_middleware_parameters(sorted_signals)
+
+    @classmethod
+    def _init_parameters(cls, sample_signal: np.ndarray, num_of_states: int
+                         ) -> Tuple[np.ndarray, np.ndarray, TransitionProbabilities]:
+        """hidden_markov_model.py:359-389: means from a uniform split of the FIRST utterance,
+        covariances 0.01 I, uniform upper-triangular transitions."""
+        seg = int(sample_signal.shape[0] / num_of_states)
+        means = [np.average(sample_signal[i * seg: i * seg + seg, :], axis=0) for i in range(num_of_states)]
+        return (np.array(means, dtype=np.float32), cls._init_covariance(sample_signal.shape[1], num_of_states),
+                TransitionProbabilities.from_num_of_states(num_of_states))
+
+    @staticmethod
+    def _init_covariance(dim_of_features: int, num_of_states: int) -> np.ndarray:
+        return (np.tile(np.eye(dim_of_features), (num_of_states, 1, 1)) * 0.01).astype(np.float32)
+
+    @staticmethod
+    def get_multivariate_normals(means: np.ndarray, covariances: np.ndarray) -> List[MultivariateNormal]:
+        return [MultivariateNormal.from_means_covariances(mean=m, covariance=c) for m, c in zip(means, covariances)]
+
+    def _arrays_to_save(self) -> Dict[str, np.ndarray]:
+        out = super()._arrays_to_save()
+        if hasattr(self, "_means"):
+            out.update(means=self._means, covariances=self._covariances, trans=self._transition_probs.to_array())
+        return out
+
+    def _load_arrays(self, z) -> None:
+        super()._load_arrays(z)
+        if "means" in z.files:
+            self._means, self._covariances = z["means"], z["covariances"]
+            self._transition_probs = TransitionProbabilities.from_transition_probability(z["trans"])
+
+
+def _stack(models: Sequence[HiddenMarkovModel]) -> Tuple[LogTransitionProbabilities, List[MultivariateNormal], ModelBoundary]:
+    ltp = LogTransitionProbabilities()
+    mvn: List[MultivariateNormal] = []
+    mb = ModelBoundary()
+    for m in models:
+        ltp.append(m._log_transition_probs)
+        mvn.extend(m._multivariate_normals)
+        mb.append(len(m._multivariate_normals))
+    mb.add_model_labels([str(m) for m in models])
+    return ltp, mvn, mb
+
+
+@dataclass
+class HiddenMarkovModelInference:
+    """Connected-word decoder over a free word loop (hidden_markov_model.py:413-581)."""
+
+    _multivariate_normals: List[MultivariateNormal] = field(default_factory=list)
+    _log_transition_probs: LogTransitionProbabilities = field(init=False)
+    _model_boundaries: ModelBoundary = field(init=False)
+    _log_transition_probability_between_words: float = field(default=np.log(0.005))
+
+    @classmethod
+    def from_folder(cls, folder_path: str, models_to_load: List[str]):
+        """Word models are stacked in sorted(os.listdir) order (hidden_markov_model.py:421-456)."""
+        models = []
+        for name in sorted(os.listdir(folder_path)):
+            path = os.path.join(folder_path, name)
+            if HiddenMarkovModel._model_folder_name_parser(path) in models_to_load:
+                models.append(HiddenMarkovModel.from_folder(path))
+        return cls.from_models(models)
+
+    @classmethod
+    def from_models(cls, models: Sequence[HiddenMarkovModel]):
+        inf = cls()
+        inf._log_transition_probs, inf._multivariate_normals, inf._model_boundaries = _stack(models)
+        return inf
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_dev_cache", None)
+        return state
+
+    def _bind(self):
+        """Upload model + loop graph if this object's arrays are not the ones on the device."""
+        eng = _native.get_engine()
+        cache = self.__dict__.get("_dev_cache")
+        if cache is None or cache["src"] is not self._multivariate_normals:
+            mb = self._model_boundaries
+            lower, upper = mb.lower_boundaries, mb.upper_boundaries
+            lower_of = np.zeros(mb.num_of_states, dtype=np.int64)
+            for lo, up in zip(lower, upper):
+                lower_of[lo:up + 1] = lo
+            silence = mb._labels.index("S") if "S" in mb._labels else -1
+            cache = {"token": _native.new_token(), "src": self._multivariate_normals,
+                     "model": stack_gaussians(self._multivariate_normals),
+                     "graph": (self._log_transition_probs.band(lower_of), lower, upper, silence)}
+            self.__dict__["_dev_cache"] = cache
+        eng.set_model(cache["token"], *cache["model"])
+        eng.set_loop_graph(cache["token"], *cache["graph"])
+        eng.set_between(self._log_transition_probability_between_words)
+        return eng
+
+    def _labels_from_device(self, eng, fb, labels, n_labels, label_cap: int) -> List[str]:
+        names = self._model_boundaries._labels
+        lab = labels.cpu().numpy()
+        cnt = n_labels.cpu().numpy()
+        out = ["".join(names[w] for w in lab[i, :min(int(cnt[i]), label_cap)]) for i in range(fb.n)]
+        over = np.nonzero(cnt > label_cap)[0]
+        if over.shape[0]:                       # more words than the fixed-width record holds: re-read from the path
+            _, paths, _, _ = eng.decode_loop(fb, want_paths=True, label_cap=label_cap)
+            plist = _native.split_ragged(paths.cpu().numpy(), fb.host_off)
+            for i in over:
+                out[i] = "".join(self._model_boundaries.get_labels(plist[i]))
+        return out
+
+    def predict(self, signal: np.ndarray) -> str:
+        return self.predict_batch([signal])[0]
+
+    def predict_batch(self, signals, label_cap: int = 32) -> List[str]:
+        """Decoded label strings for a list of (T, 39) arrays (or a FeatureBatch) in one device call."""
+        eng = self._bind()
+        fb = signals if isinstance(signals, _native.FeatureBatch) else eng.feature_batch(signals)
+        if fb.lengths.min() < 2:
+            raise Exception("Failed to find lower boundary for state -1")     # reference: get_labels on path [-1]
+        _, _, labels, n_labels = eng.decode_loop(fb, want_paths=False, label_cap=label_cap)
+        return self._labels_from_device(eng, fb, labels, n_labels, label_cap)
+
+    def recognize_audio(self, signals, label_cap: int = 32) -> List[str]:
+        """Audio in, label strings out: MFCC + decode without the features leaving the device
+        (the per-utterance work of scripts/project5_test_ndigits_with_sil.py:64-77)."""
+        eng = self._bind()
+        ab = signals if isinstance(signals, _native.AudioBatch) else eng.audio_batch(signals)
+        _, _, labels, n_labels = eng.recognize(ab, want_paths=False, label_cap=label_cap)
+        cnt = n_labels.cpu().numpy()
+        if (cnt > label_cap).any():
+            return self.predict_batch(eng.mfcc(ab), label_cap=label_cap)
+        names = self._model_boundaries._labels
+        lab = labels.cpu().numpy()
+        return ["".join(names[w] for w in lab[i, :int(cnt[i])]) for i in range(ab.n)]
+
+    def _viterbi(self, observation_sequence: np.ndarray) -> Tuple[np.float32, np.ndarray]:
+        return self.viterbi_batch([observation_sequence])[0]
+
+    def viterbi_batch(self, signals) -> List[Tuple[np.float32, np.ndarray]]:
+        eng = self._bind()
+        fb = signals if isinstance(signals, _native.FeatureBatch) else eng.feature_batch(signals)
+        scores, paths, _, _ = eng.decode_loop(fb, want_paths=True)
+        scores = scores.cpu().numpy()
+        plist = _native.split_ragged(paths.cpu().numpy(), fb.host_off)
+        return [(scores[i], plist[i]) for i in range(fb.n)]
+
+
+@dataclass
+class HiddenMarkovModelMultiWord(HiddenMarkovModel):
+    """Forced-alignment chain for a known label string (hidden_markov_model.py:584-664)."""
+    _model_boundaries: ModelBoundary = field(init=False)
+
+    @classmethod
+    def from_labels(cls, labels: str, trainable_models: Dict[str, HiddenMarkovModelTrainable]):
+        hmm = cls(labels)
+        hmm.isTqdm = False
+        hmm._log_transition_probs, hmm._multivariate_normals, hmm._model_boundaries = _stack(
+            [_Labelled(lab, trainable_models[lab]) for lab in labels])
+        return hmm
+
+    def get_remuexed_signals(self, mfccs_sequences: List[np.ndarray]) -> Dict[str, List[Signal]]:
+        out: Dict[str, List[Signal]] = {lab: [] for lab in self._model_boundaries._labels}
+        for x, (_, path) in zip(mfccs_sequences, self.predict_batch(mfccs_sequences)):
+            for lab, sigs in self._remux_path_and_signal(x, path, self._model_boundaries).items():
+                out[lab].extend(sigs)
+        return out
+
+    @staticmethod
+    def _remux_path_and_signal(signal: np.ndarray, path: np.ndarray, model_boundaries: ModelBoundary
+                               ) -> Dict[str, List[Signal]]:
+        """hidden_markov_model.py:602-636: cut wherever the word label changes; a piece is only
+        emitted by the change that ends it, so the final piece is dropped."""
+        out: Dict[str, List[Signal]] = {lab: [] for lab in model_boundaries._labels}
+        begin = 0
+        cur_state = int(path[0])
+        cur_label = model_boundaries.get_label(cur_state)
+        for i, st in enumerate(path):
+            lab = model_boundaries.get_label(int(st))
+            if lab != cur_label:
+                lo = model_boundaries.find_lower_boundary(cur_state)
+                hi = model_boundaries.find_upper_boundary(cur_state)
+                out[cur_label].append(Signal(num_of_state=hi - lo + 1, signal=signal[begin:i], path=path[begin:i] - lo))
+                begin, cur_state = i, int(path[i])
+                cur_label = model_boundaries.get_label(cur_state)
+        return out
+
+
+class _Labelled:
+    """Adapter: a word model seen under the label it has in a chain."""
+
+    def __init__(self, label: str, model: HiddenMarkovModel):
+        self._label = label
+        self._log_transition_probs = model._log_transition_probs
+        self._multivariate_normals = model._multivariate_normals
+
+    def __str__(self) -> str:
+        return self._label
+
+
+@dataclass
+class HiddenMarkovModelTrainContinuous:
+    """Continuous-speech re-training of all word models (hidden_markov_model.py:667-797)."""
+    isTqdm: bool = field(default=True)
+    isMultiProcessing: bool = field(default=True)     # interface compatibility; the batch replaces the pool
+
+    _trainable_models: Dict[str, HiddenMarkovModelTrainable] = field(default_factory=dict)
+    _models_loaded: List[str] = field(default_factory=list)
+    _num_of_finished_models: int = field(default=0)
+
+    @classmethod
+    def from_folder(cls, folder_path: str, models_to_load: List[str]):
+        obj = cls()
+        for name in sorted(os.listdir(folder_path)):
+            path = os.path.join(folder_path, name)
+            label = HiddenMarkovModel._model_folder_name_parser(path)
+            if label not in models_to_load:
+                continue
+            obj.add_model(HiddenMarkovModelTrainable.from_folder(path))
+        obj._models_loaded = models_to_load
+        return obj
+
+    def add_model(self, m: HiddenMarkovModelTrainable) -> None:
+        """Register a word model the way from_folder does (hidden_markov_model.py:692-707): the
+        inference weights are kept, the trainable parameters restart from zeros / 0.01 I /
+        uniform so that the first iteration can never report convergence."""
+        n = len(m._multivariate_normals)
+        d = m._multivariate_normals[0].dim_of_features
+        m._means = np.zeros((n, d), dtype=np.float32)
+        m._covariances = m._init_covariance(d, n)
+        m._transition_probs = TransitionProbabilities.from_num_of_states(n)
+        self._trainable_models[m.label] = m
+        if m.label not in self._models_loaded:
+            self._models_loaded.append(m.label)
+
+    # -- one iteration on the device --------------------------------------------------------------------
+    def _layout(self) -> Tuple[Dict[str, int], int]:
+        base, n = {}, 0
+        for lab in self._models_loaded:
+            base[lab] = n
+            n += self._trainable_models[lab].num_of_states
+        return base, n
+
+    def _prepare(self, labeled_mfccs: Dict[str, List[np.ndarray]]):
+        """Upload the utterances once; remember which label string each one carries."""
+        key = id(labeled_mfccs)
+        cache = self.__dict__.get("_data_cache")
+        if cache is None or cache["key"] != key:
+            eng = _native.get_engine()
+            utts, owner = [], []
+            for digits, seqs in labeled_mfccs.items():
+                utts.extend(seqs)
+                owner.extend([digits] * len(seqs))
+            cache = {"key": key, "fb": eng.feature_batch(utts), "owner": owner}
+            self.__dict__["_data_cache"] = cache
+        return cache["fb"], cache["owner"]
+
+    def _align(self, fb, owner: List[str]):
+        """Forced alignment of every utterance against S d S d ... S (hidden_markov_model.py:772-782)
+        in one device call.  Returns per-frame arrays: path (chain position), global model state,
+        ordinal of the word within its chain."""
+        eng = _native.get_engine()
+        base, n_total = self._layout()
+        models = [self._trainable_models[lab] for lab in self._models_loaded]
+        eng.set_model(_native.new_token(), *stack_gaussians([g for m in models for g in m._multivariate_normals]))
+        per_string = {}
+        for digits in dict.fromkeys(owner):
+            chain = self.insert_silence(digits)
+            ltp, _, mb = _stack([_Labelled(c, self._trainable_models[c]) for c in chain])
+            ids = np.concatenate([base[c] + np.arange(self._trainable_models[c].num_of_states) for c in chain])
+            ordinal = np.concatenate([np.full(self._trainable_models[c].num_of_states, k) for k, c in enumerate(chain)])
+            start = np.zeros(ids.shape[0], dtype=np.uint8)
+            start[0] = 1
+            per_string[digits] = (ids.astype(np.int32), ltp.band(), start, ordinal.astype(np.int32))
+        lens = np.array([per_string[d][0].shape[0] for d in owner], dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = np.concatenate([per_string[d][0] for d in owner])
+        band = np.concatenate([per_string[d][1] for d in owner], axis=1)
+        start = np.concatenate([per_string[d][2] for d in owner])
+        ordinal = np.concatenate([per_string[d][3] for d in owner])
+        _, paths, _ = eng.decode_chain(fb, off, ids, band, start)
+        path = paths.cpu().numpy().astype(np.int64)
+        utt_of_frame = np.repeat(np.arange(fb.n), fb.lengths)
+        pos = off[utt_of_frame] + path
+        return path, ids[pos].astype(np.int64), ordinal[pos].astype(np.int64), utt_of_frame, n_total
+
+    def _iteration(self, labeled_mfccs: Dict[str, List[np.ndarray]]) -> None:
+        """Alignment + re-mux + statistics + per-word M-step (hidden_markov_model.py:733-770) without
+        materialising per-word Signal objects: a frame contributes to the model state it is aligned
+        to unless it belongs to the last word run of its utterance (the reference never flushes that
+        run, hidden_markov_model.py:614-634)."""
+        eng = _native.get_engine()
+        fb, owner = self._prepare(labeled_mfccs)
+        _, gstate, ordinal, utt, n_total = self._align(fb, owner)
+        last_ord = ordinal[fb.host_off[1:] - 1]
+        keep = ordinal != last_ord[utt]
+        slots = np.where(keep, gstate, -1).astype(np.int32)
+        count, sum_x, sum_xx = eng.accumulate_stats(fb.feats, eng.to_device(slots), fb.total_frames, n_total)
+        pair = keep[:-1] & keep[1:] & (utt[:-1] == utt[1:]) & (ordinal[:-1] == ordinal[1:])
+        trans = np.bincount(gstate[:-1][pair] * n_total + gstate[1:][pair], minlength=n_total * n_total)
+        trans = trans.reshape(n_total, n_total).astype(np.float64)
+        stats = eng.torch.cat([count, sum_x.reshape(-1), sum_xx.reshape(-1), eng.to_device(trans.reshape(-1))])
+        stats = all_reduce_stats(stats)
+        stats = stats.cpu().numpy()
+        d = _native.DIM
+        count = stats[:n_total]
+        sum_x = stats[n_total:n_total * (1 + d)].reshape(n_total, d)
+        sum_xx = stats[n_total * (1 + d):n_total * (1 + d + d * d)].reshape(n_total, d, d)
+        trans = stats[n_total * (1 + d + d * d):].reshape(n_total, n_total)
+        base, _ = self._layout()
+        self._m_steps(base, count, sum_x, sum_xx, trans)
+
+    def _m_steps(self, base, count, sum_x, sum_xx, trans) -> None:
+        """hidden_markov_model.py:754-770, including the never-reset convergence counter."""
+        for lab in self._models_loaded:
+            m = self._trainable_models[lab]
+            lo, hi = base[lab], base[lab] + m.num_of_states
+            try:
+                m._m_step(count[lo:hi], sum_x[lo:hi], sum_xx[lo:hi], trans[lo:hi, lo:hi])
+            except HiddenMarkovModelTrainable.HMMTrainConverge:
+                self._num_of_finished_models += 1
+                if self._num_of_finished_models == len(self._trainable_models):
+                    raise
+            finally:
+                m._update_inference_weights()
+
+    def train(self, labeled_mfccs: Dict[str, List[np.ndarray]], max_iterations: int = 100) -> None:
+        bar = tqdm(total=max_iterations, desc="Training Iteration", disable=not self.isTqdm, position=0)
+        for _ in range(max_iterations):
+            try:
+                self._iteration(labeled_mfccs)
+            except HiddenMarkovModelTrainable.HMMTrainMeanFail:
+                logger.error("Failed to train model")
+                raise
+            except HiddenMarkovModelTrainable.HMMTrainConverge:
+                break
+            bar.update()
+        bar.close()
+
+    # -- reference-shaped two-step interface -------------------------------------------------------------
+    def _train(self, labeled_mfccs: Dict[str, List[np.ndarray]]) -> Dict[str, List[Signal]]:
+        """Re-muxed per-word Signal lists as the reference returns them (hidden_markov_model.py:733-752)."""
+        out: Dict[str, List[Signal]] = {lab: [] for lab in self._models_loaded}
+        for item in labeled_mfccs.items():
+            for lab, sigs in self._train_process(item).items():
+                out[lab].extend(sigs)
+        return out
+
+    def _train_process(self, labels_and_mfccs: Tuple[str, List[np.ndarray]]) -> Dict[str, List[Signal]]:
+        labels, mfccs = labels_and_mfccs
+        hmm = HiddenMarkovModelMultiWord.from_labels(self.insert_silence(labels), self._trainable_models)
+        return hmm.get_remuexed_signals(mfccs)
+
+    def _update_trainable_model_parameters(self, remuxed_signals: Dict[str, List[Signal]]) -> None:
+        for label, signals in remuxed_signals.items():
+            try:
+                self._trainable_models[label]._train_external(signals)
+            except HiddenMarkovModelTrainable.HMMTrainConverge:
+                self._num_of_finished_models += 1
+                if self._num_of_finished_models == len(self._trainable_models):
+                    raise
+            finally:
+                self._trainable_models[label]._update_inference_weights()
+
+    def save(self, folder_path: str) -> None:
+        os.makedirs(folder_path, exist_ok=True)
+        for model in self._trainable_models.values():
+            model.save(folder_path)
+
+    @staticmethod
+    def insert_silence(labels: str) -> str:
+        return "".join(f"S{c}" for c in labels) + "S"
+
+
+def all_reduce_stats(stats):
+    """Sum the packed float64 statistics over all ranks (one RCCL all-reduce per training
+    iteration) when torch.distributed is initialised; identity otherwise."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    return stats

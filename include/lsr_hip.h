@@ -1,0 +1,163 @@
+/*
+ * lsr_hip.h - C ABI of liblsr_hip.so: MFCC front-end, Gaussian emission scores and
+ * Viterbi decoding of left-to-right HMM word models on one AMD MI355X (gfx950).
+ *
+ * The library is the device half of a drop-in for the numeric hot path of the Python
+ * package `loe_speech_recognition`.  That package has no FFI of its own; every entry point
+ * below names the Python method(s) it replaces (paths relative to
+ * src/loe_speech_recognition/ of the reference repository).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative LSR_ERR_* code on failure;
+ *     lsr_last_error(ctx) returns a human-readable message for the last failure on ctx.
+ *   - one context per (process, device).  A context is not thread-safe.
+ *   - "_d" parameters are DEVICE pointers owned by the caller (e.g. torch tensors); all other
+ *     pointers are host pointers.  Nothing is retained after a call returns except what
+ *     lsr_model_upload / lsr_loop_graph_upload copy to the device.
+ *   - ragged batches are one concatenated buffer plus int64 offsets[B+1] (offsets[0] = 0).
+ *   - kernels are enqueued on the context's stream (lsr_set_stream, default: the null stream);
+ *     calls are asynchronous with respect to the host unless stated otherwise.
+ *   - internal workspace grows on demand (hipMalloc) and is reused; a steady-state loop over
+ *     batches no larger than an earlier one allocates nothing.
+ *   - feature dimension is fixed at LSR_DIM = 39, at most LSR_MAX_STATES = 64 states per
+ *     decoding graph / alignment chain.
+ */
+#ifndef LSR_HIP_H
+#define LSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSR_DIM 39
+#define LSR_MAX_STATES 64
+#define LSR_LL_STRIDE 64      /* row stride (floats) of emission score matrices */
+#define LSR_N_FFT 320
+#define LSR_HOP 160
+#define LSR_N_MELS 40
+#define LSR_N_BINS 161
+#define LSR_N_MFCC 13
+
+#define LSR_OK 0
+#define LSR_ERR_ARG (-1)      /* invalid argument / shape */
+#define LSR_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define LSR_ERR_LIMIT (-3)    /* size beyond a documented limit */
+#define LSR_ERR_STATE (-4)    /* call order: model or graph not uploaded yet */
+
+typedef struct lsr_ctx lsr_ctx;
+
+/* kernel ids for lsr_profile_get */
+#define LSR_K_FRAME_INDEX 0
+#define LSR_K_MEL_POWER 1
+#define LSR_K_MFCC_FINISH 2
+#define LSR_K_EMISSION 3
+#define LSR_K_VITERBI 4
+#define LSR_K_STATS 5
+#define LSR_K_COUNT 6
+
+/* ---- context ---------------------------------------------------------------------------- */
+int lsr_ctx_create(int device, lsr_ctx** out);
+int lsr_ctx_destroy(lsr_ctx* ctx);
+const char* lsr_last_error(const lsr_ctx* ctx);
+int lsr_set_stream(lsr_ctx* ctx, void* hip_stream);   /* hipStream_t; NULL = null stream */
+int lsr_synchronize(lsr_ctx* ctx);                    /* blocks until the stream is idle  */
+
+/* Per-kernel device time, measured with HIP events on the context's stream around every
+ * launch while enabled (adds two event records per launch).  lsr_profile_get synchronises. */
+int lsr_profile_enable(lsr_ctx* ctx, int on);
+int lsr_profile_reset(lsr_ctx* ctx);
+int lsr_profile_get(lsr_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+
+/* ---- host-only table builders (no GPU needed; used by the front-end and by tests) -------- */
+void lsr_host_hann_window(double* out320);            /* periodic Hann, n_fft = 320            */
+void lsr_host_mel_filterbank(float* out40x161);       /* Slaney mel, 16 kHz, 133.33-6855.4976  */
+void lsr_host_dct_matrix(double* out13x40);           /* DCT-II, orthonormal, first 13 rows    */
+
+/* ---- model ------------------------------------------------------------------------------ */
+/* Replaces MultivariateNormal.from_means_covariances (hidden_markov_model.py:27-44): the
+ * state of n_states frozen full-covariance Gaussians.  mean[S][39]; whiten[S][39][39] is
+ * SciPy's U = V * diag(lambda^-1/2) with whiten[s][k][j] multiplying feature k into whitened
+ * component j; log_norm[s] = 39*log(2*pi) + log|Sigma_s|.  All float64, host memory. */
+int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, const double* whiten,
+                     const double* log_norm);
+
+/* Replaces the state space built by HiddenMarkovModelInference.from_folder
+ * (hidden_markov_model.py:421-456): word models stacked in order, band[d][s] =
+ * log a(s-d -> s) for d = 0,1,2 (-inf where s-d is not a candidate predecessor: before the
+ * word's first state), word_lower/word_upper[w] = first/last state of word w (ascending).
+ * silence_word = index of the word dropped from label output (-1: none). */
+int lsr_loop_graph_upload(lsr_ctx* ctx, int n_states, int n_words, const float* band,
+                          const int32_t* word_lower, const int32_t* word_upper, int silence_word);
+/* The writable attribute _log_transition_probability_between_words
+ * (hidden_markov_model.py:419).  between_is_f64 != 0 reproduces an np.float64 value (the
+ * class default np.log(0.005)): the cross-word candidate is then added in float64;
+ * otherwise `between` is rounded to float32 and added in float32 (Python int/float). */
+int lsr_loop_set_between(lsr_ctx* ctx, double between, int between_is_f64);
+
+/* ---- front-end -------------------------------------------------------------------------- */
+/* Replaces MFCC.batch (mfcc.py:71-84; per clip mfcc.py:24-44,50-69).  audio_d: float32
+ * samples of B clips back to back; sample_off_d[B+1]; frame_off_d[B+1] with
+ * frames(b) = 1 + samples(b) / 160 (>= 9 each).  feats_d: float32 [total_frames][39]
+ * (time-major, the transposed layout MFCC.batch returns). */
+int lsr_mfcc_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+                   const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d);
+
+/* ---- emission scores -------------------------------------------------------------------- */
+/* Replaces MultivariateNormal.log_pdf (hidden_markov_model.py:46-48) for every (frame, state):
+ * ll_d[f][s] = float32( -0.5 * (log_norm[s] + |(x_f - mean_s) @ whiten_s|^2) ), float64
+ * inside.  ll_d: float32 [round_up(total_frames, 64)][LSR_LL_STRIDE]; columns >= n_states
+ * are -inf. */
+int lsr_emission_batch(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d);
+
+/* ---- decoding --------------------------------------------------------------------------- */
+/* Replaces HiddenMarkovModelInference.predict/_viterbi/_viterbi_static
+ * (hidden_markov_model.py:458-581) plus ModelBoundary.get_labels (model_boundary.py:107-147)
+ * for a batch.  Outputs (any may be NULL): scores_d float32[B]; paths_d int8[total_frames]
+ * (ragged like the features); labels_d uint8[B][label_cap] word indices in decode order with
+ * the silence word removed; n_labels_d int32[B] = number of labels found (may exceed
+ * label_cap; only the first label_cap are stored). */
+int lsr_decode_loop_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d,
+                          int n_utts, int64_t total_frames, int max_frames, float* scores_d,
+                          int8_t* paths_d, uint8_t* labels_d, int32_t* n_labels_d, int label_cap);
+
+/* Same, starting from audio: lsr_mfcc_batch + lsr_decode_loop_batch with the features kept in
+ * the workspace (what project5_test_ndigits_with_sil.py:64-77 does per utterance). */
+int lsr_recognize_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+                        const int64_t* frame_off_d, int n_utts, int64_t total_frames,
+                        int max_frames, float* scores_d, int8_t* paths_d, uint8_t* labels_d,
+                        int32_t* n_labels_d, int label_cap);
+
+/* Replaces HiddenMarkovModel.predict/_viterbi/_viterbi_static (hidden_markov_model.py:75-91,
+ * 160-208) for a batch of per-utterance chains: isolated word models, several independent
+ * models side by side (ModelCollection.predict, model_collection.py:23-28) or the stacked
+ * alignment chain S d S d ... S of HiddenMarkovModelMultiWord (hidden_markov_model.py:584-664).
+ * Chain b has chain_off_d[b+1]-chain_off_d[b] <= 64 states; for chain position c (ragged
+ * index i = chain_off_d[b] + c): chain_state_d[i] = model state whose Gaussian it uses,
+ * chain_band_d[d*total_chain + i] = log a(c-d -> c) (float32; 0.0 for the reference's
+ * missing cross-word keys, -inf to forbid), chain_start_d[i] != 0 marks states initialised at
+ * frame 0.  The path is traced back from the chain's LAST state.  Outputs (any may be NULL):
+ * scores_d float32[B] (likelihood of the last state), paths_d int8[total_frames] (chain
+ * positions), final_d float32[B][64] (last-frame likelihood of every chain position). */
+int lsr_decode_chain_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d,
+                           int n_utts, int64_t total_frames, int max_frames,
+                           const int64_t* chain_off_d, int64_t total_chain,
+                           const int32_t* chain_state_d, const float* chain_band_d,
+                           const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d,
+                           float* final_d);
+
+/* ---- hard-alignment statistics ---------------------------------------------------------- */
+/* Replaces the data reduction of SortedSignals.order_by_state / .transition_probabilities and
+ * HiddenMarkovModelTrainable._update_middleware_parameters (signal.py:68-91,
+ * hidden_markov_model.py:320-350): given per-frame target slots slot_d[f] in [0, n_slots) or -1
+ * (frame not used), accumulates in float64  count[n_slots], sum_x[n_slots][39],
+ * sum_xx[n_slots][39][39].  The three outputs are device pointers and are OVERWRITTEN. */
+int lsr_accumulate_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d,
+                         int64_t total_frames, int n_slots, double* count_d, double* sum_x_d,
+                         double* sum_xx_d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSR_HIP_H */
