@@ -1,0 +1,152 @@
+"""HIP path (through the C ABI, behind the drop-in classes) against fixtures computed by the
+real reference code.  Scores, paths and label strings must be identical; emission scores are
+float64 inside and may differ from SciPy's BLAS summation order by one float32 ulp on rare
+elements (tolerance of the task: 1e-4 relative)."""
+import numpy as np
+import pytest
+
+from helpers import BETWEEN, LOOP_LABELS, load, loop_decoder, rel_err, trainable, trans_close, word
+
+pytestmark = pytest.mark.gpu
+
+
+def test_g1_emission():
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainable, _native
+    from loe_speech_recognition_amd.hidden_markov_model import stack_gaussians
+
+    g = load("hmm_g1_emission.npz")
+    mvn = HiddenMarkovModelTrainable.get_multivariate_normals(g["means"], g["cov"])
+    assert np.array_equal(np.stack([m.whiten for m in mvn[:4]]), g["U_first4"])
+    assert np.array_equal(np.array([m.log_pdet for m in mvn]), g["logdet"])
+    eng = _native.get_engine()
+    eng.set_model(None, *stack_gaussians(mvn))
+    ll = eng.emission(eng.feature_batch([g["x"]])).cpu().numpy()
+    got, ref = ll[:64, :58], g["ll"]
+    assert rel_err(got, ref) <= 1e-4
+    assert np.all(np.abs(got - ref) <= np.spacing(np.abs(ref)))
+    assert np.mean(got != ref) < 2e-3
+    assert np.all(np.isneginf(ll[:64, 58:]))
+    # single-vector interface (hidden_markov_model.py:46-48)
+    v = mvn[7].log_pdf(g["x"][3])
+    assert v.dtype == np.float32 and abs(v - ref[3, 7]) <= np.spacing(abs(ref[3, 7]))
+
+
+@pytest.mark.parametrize("n", [3, 5])
+def test_g2_single_model(n):
+    g = load("hmm_g2_single.npz")
+    m = trainable("w", g[f"n{n}_means"], g[f"n{n}_cov"], g[f"n{n}_trans"])
+    tags = ("T9", "T50", "T200", "late")
+    out = m.predict_batch([g[f"n{n}_{t}_x"] for t in tags])
+    for tag, (score, path) in zip(tags, out):
+        assert score == g[f"n{n}_{tag}_score"], tag
+        assert path.dtype == np.int8 and np.array_equal(path, g[f"n{n}_{tag}_path"]), tag
+    score, path = m.predict(g[f"n{n}_T50_x"])
+    assert isinstance(score, np.float32) and score == g[f"n{n}_T50_score"]
+
+
+@pytest.mark.parametrize("tag", ["n35", "n59"])
+def test_g2_alignment_chain(tag):
+    from loe_speech_recognition_amd import HiddenMarkovModelMultiWord
+
+    g = load("hmm_g2_single.npz")
+    words = {lab: word(g, f"chain_{lab}", lab) for lab in "123S"}
+    hmm = HiddenMarkovModelMultiWord.from_labels(str(g[f"{tag}_chain"]), words)
+    assert hmm.num_of_states == int(tag[1:])
+    for T in (50, 200):
+        if f"{tag}_T{T}_x" not in g.files:
+            continue
+        score, path = hmm.predict(g[f"{tag}_T{T}_x"])
+        assert score == g[f"{tag}_T{T}_score"]
+        assert np.array_equal(path, g[f"{tag}_T{T}_path"])
+
+
+def test_g3_loop_decode():
+    g = load("hmm_g3_loop.npz")
+    inf = loop_decoder(g)
+    n = int(g["n_utts"])
+    xs = [g[f"u{i}_x"] for i in range(n)]
+    for tag, between in BETWEEN.items():
+        inf._log_transition_probability_between_words = between
+        labels = inf.predict_batch(xs)
+        vit = inf.viterbi_batch(xs)
+        for i in range(n):
+            assert vit[i][0] == g[f"u{i}_{tag}_score"], (i, tag)
+            assert np.array_equal(vit[i][1], g[f"u{i}_{tag}_path"]), (i, tag)
+            assert labels[i] == str(g[f"u{i}_{tag}_labels"]), (i, tag)
+    inf._log_transition_probability_between_words = -100
+    assert inf.predict(xs[4]) == str(g["u4_m100_labels"])
+
+
+def test_g5_isolated_train_step():
+    g = load("hmm_g5_training.npz")
+    m = trainable("w", g["a_means0"], g["a_cov0"], g["a_trans0"])
+    m._train([g[f"a_x{i}"] for i in range(int(g["a_n"]))])
+    assert rel_err(m._means, g["a_means1"]) <= 1e-4
+    assert rel_err(m._covariances, g["a_cov1"]) <= 1e-4
+    assert trans_close(m._transition_probs.to_array(), g["a_trans1"])
+
+
+def test_g5_from_data():
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainable
+
+    g = load("hmm_g5_training.npz")
+    utts = [g[f"b_x{i}"] for i in range(int(g["b_n"]))]
+    m = HiddenMarkovModelTrainable.from_data("w", utts, num_of_states=5, max_iterations=6, isTqdm=False)
+    assert rel_err(m._means, g["b_means"]) <= 1e-4
+    assert rel_err(m._covariances, g["b_cov"]) <= 1e-4
+    assert trans_close(m._transition_probs.to_array(), g["b_trans"])
+    score, path = m.predict(utts[0])
+    assert path[0] == 0 and np.all(np.diff(path) >= 0)
+
+
+def _continuous(g):
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainContinuous
+
+    tc = HiddenMarkovModelTrainContinuous(isTqdm=False)
+    for lab in "12OS":
+        tc._trainable_models[lab] = trainable(lab, g[f"c_{lab}_means0"], g[f"c_{lab}_cov0"], g[f"c_{lab}_trans0"])
+    tc._models_loaded = list("12OS")
+    labeled = {str(k): [g[f"c_x_{str(k)}_{i}"] for i in range(3)] for k in g["c_keys"]}
+    return tc, labeled
+
+
+def _check_continuous(tc, g):
+    for lab in "12OS":
+        t = tc._trainable_models[lab]
+        assert rel_err(t._means, g[f"c_{lab}_means1"]) <= 1e-4, lab
+        assert rel_err(t._covariances, g[f"c_{lab}_cov1"]) <= 1e-4, lab
+        assert trans_close(t._transition_probs.to_array(), g[f"c_{lab}_trans1"]), lab
+
+
+def test_g5_continuous_iteration_fused():
+    g = load("hmm_g5_training.npz")
+    tc, labeled = _continuous(g)
+    tc._iteration(labeled)
+    _check_continuous(tc, g)
+
+
+def test_g5_continuous_iteration_reference_shaped():
+    g = load("hmm_g5_training.npz")
+    tc, labeled = _continuous(g)
+    remuxed = tc._train(labeled)
+    for lab in "12OS":
+        assert len(remuxed[lab]) == int(g[f"c_{lab}_nseg"])
+        assert np.array_equal(np.array([s.signal.shape[0] for s in remuxed[lab]]), g[f"c_{lab}_seg_frames"])
+        assert np.array_equal(np.concatenate([s.path for s in remuxed[lab]]), g[f"c_{lab}_seg_paths"])
+    tc._update_trainable_model_parameters(remuxed)
+    _check_continuous(tc, g)
+
+
+def test_g6_model_collection():
+    from loe_speech_recognition_amd import ModelCollection
+
+    g = load("hmm_g6_collection.npz")
+    labels = ["1", "2", "3", "4", "5", "6", "7", "8", "9", "O", "Z"]
+    mc = ModelCollection()
+    mc._models = [word(g, lab) for lab in labels]
+    xs = [g[f"x{i}"] for i in range(5)]
+    assert mc.predict_batch(xs) == [str(p) for p in g["preds"]]
+    scores = mc.scores_batch(xs)
+    for i in range(5):
+        assert np.array_equal(scores[i], g[f"scores{i}"])
+    assert mc.predict(xs[1]) == "2"          # "8" is a copy of "2": the earlier model wins the tie

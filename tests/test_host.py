@@ -1,0 +1,146 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, the host-side
+tables match the oracle, and the host bookkeeping classes follow the reference's rules."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import LOOP_LABELS, load
+from oracle import hmm_oracle as O
+from oracle import mfcc_oracle as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from loe_speech_recognition_amd import _native
+
+    lib = _native.load_library()
+    header = open(os.path.join(ROOT, "include", "lsr_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(lsr_[a-z0-9_]+)\s*\(", header)))
+    assert declared and sorted(_native.EXPORTED_SYMBOLS) == declared
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_host_tables_match_oracle():
+    import scipy.signal
+
+    from loe_speech_recognition_amd import _native
+
+    win, mel, dct = _native.host_tables()
+    assert np.array_equal(win, scipy.signal.get_window("hann", 320, fftbins=True))
+    ref = M.mel_filterbank()
+    assert np.all(np.abs(mel - ref) <= np.spacing(ref)) and np.mean(mel != ref) < 1e-3
+    n = np.arange(40)
+    k = np.arange(13)[:, None]
+    basis = np.cos(np.pi * k * (2 * n + 1) / 80.0) * np.sqrt(2.0 / 40)
+    basis[0] *= np.sqrt(0.5)
+    assert np.allclose(dct, basis, atol=1e-15)
+
+
+def test_engine_needs_gpu():
+    import torch
+
+    from loe_speech_recognition_amd import _native
+
+    if not torch.cuda.is_available():
+        with pytest.raises(_native.NativeError):
+            _native.Engine()
+
+
+def test_model_boundary_labels_match_reference():
+    from loe_speech_recognition_amd import ModelBoundary
+
+    g = load("hmm_g4_labels.npz")
+    mb = ModelBoundary()
+    for lab in LOOP_LABELS:
+        mb.append(3 if lab == "S" else 5)
+    mb.add_model_labels(list(LOOP_LABELS))
+    assert mb.lower_boundaries == [0, 5, 10, 15, 20, 25, 30, 35, 40, 45, 50, 53]
+    assert mb.upper_boundaries == [4, 9, 14, 19, 24, 29, 34, 39, 44, 49, 52, 57]
+    for i in range(int(g["n"])):
+        assert "".join(mb.get_labels(g[f"p{i}"])) == str(g[f"l{i}"])
+        assert "".join(mb.get_labels(g[f"p{i}"], skip_silence=False)) == str(g[f"k{i}"])
+    with pytest.raises(Exception):
+        mb.append(5)
+    assert mb.get_state_range("2") == (5, 10)
+
+
+def test_transition_store_semantics():
+    from loe_speech_recognition_amd import LogTransitionProbabilities, TransitionProbabilities
+
+    tp = TransitionProbabilities.from_num_of_states(3)
+    assert tp[(0, 0)] == np.float32(1 / 3) and tp[(1, 0)] == 0 and tp[(2, 2)] == 1
+    ltp = LogTransitionProbabilities.from_transition_probability(tp)
+    assert ltp[(1, 0)] == -np.inf and ltp[(0, 1)] == np.log(np.float32(1 / 3))
+    both = LogTransitionProbabilities()
+    both.append(ltp)
+    both.append(ltp)
+    assert both.num_of_states == 6 and both[(2, 3)] == 0.0 and both[(3, 4)] == ltp[(0, 1)]
+    band = both.band()
+    ref = O.LogTransRef.from_probs(tp.to_array())
+    stacked = O.LogTransRef()
+    stacked.append(ref)
+    stacked.append(ref)
+    assert np.array_equal(band, O.band_from_ltp(stacked, 6))
+    assert band[1, 3] == 0.0 and band[2, 3] == 0.0 and np.isneginf(band[1, 0])
+    floor = both.band([0, 0, 0, 3, 3, 3])
+    assert np.isneginf(floor[1, 3]) and np.isneginf(floor[2, 4]) and floor[1, 4] == band[1, 4]
+
+
+def test_signal_grouping_and_remux_match_oracle():
+    from loe_speech_recognition_amd import HiddenMarkovModelMultiWord, ModelBoundary, Signal, SortedSignals
+
+    rng = np.random.default_rng(0)
+    frames = rng.standard_normal((9, 39)).astype(np.float32)
+    path = np.array([0, 0, 2, 2, 3, 3, 3, 1, 4], dtype=np.int8)
+    parts = Signal(5, frames, path).order_by_state
+    ref = O.split_by_state(5, frames, path)
+    for a, b in zip(parts, ref):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    ss = SortedSignals(5)
+    ss.append(Signal(5, frames, np.array([0, 0, 1, 1, 2, 3, 3, 4, 4], dtype=np.int8)))
+    assert ss.transition_counts[0, 0] == 1 and ss.transition_counts[3, 4] == 1
+    mb = ModelBoundary()
+    for n in (3, 5, 3):
+        mb.append(n)
+    mb.add_model_labels(["S", "1", "S"])
+    p = np.array([0, 1, 2, 3, 4, 6, 7, 8, 9], dtype=np.int8)
+    got = HiddenMarkovModelMultiWord._remux_path_and_signal(frames, p, mb)
+    exp = O.remux(frames, p, O.BoundariesRef([3, 5, 3], ["S", "1", "S"]))
+    assert {k: len(v) for k, v in got.items()} == {k: len(v) for k, v in exp.items()} == {"S": 1, "1": 1}
+    assert np.array_equal(got["1"][0].path, exp["1"][0][2]) and got["1"][0].num_of_state == 5
+
+
+def test_insert_silence():
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainContinuous
+
+    assert HiddenMarkovModelTrainContinuous.insert_silence("4Z2") == "S4SZS2S" == O.insert_silence("4Z2")
+
+
+def test_mfcc_input_validation_needs_no_gpu():
+    from loe_speech_recognition_amd import MFCC
+
+    with pytest.raises(TypeError):
+        MFCC([0.0] * 2000, 16000)
+    with pytest.raises(ValueError):
+        MFCC(np.zeros((2, 2000), np.float32), 16000)
+    with pytest.raises(ValueError):
+        MFCC(np.zeros(2000, np.float32), 8000)
+
+
+def test_synthetic_models_load_and_are_positive_definite():
+    from loe_speech_recognition_amd import synthetic
+
+    arrays = synthetic.load_word_arrays()
+    assert sorted(arrays) == sorted(synthetic.WORDS + ["S"])
+    for lab, (means, cov, trans) in arrays.items():
+        n = 3 if lab == "S" else 5
+        assert means.shape == (n, 39) and cov.shape == (n, 39, 39) and trans.shape == (n, n)
+        for c in cov:
+            assert np.linalg.eigvalsh(c.astype(np.float64)).min() > 0
+    sig, truth = synthetic.utterance(3, 0, 4)
+    sig2, truth2 = synthetic.utterance(3, 0, 4)
+    assert truth == truth2 and np.array_equal(sig, sig2) and sig.dtype == np.float32
