@@ -1,0 +1,225 @@
+"""Headline benchmark: utterances/s for connected-digit decode of synthetic 16 kHz four-digit
+clips (BASELINE.json config 3: MFCC + 58-state free-loop Viterbi, between-word penalty -100),
+audio resident in HBM, one process per GPU.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path (audio -> MFCC -> emission scores -> Viterbi -> label
+records [-> all-gather of the label records when N > 1]) over this rank's 10 000 clips.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import functools
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "cs-304-speech-recognition-code_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from loe_speech_recognition_amd import synthetic  # noqa: E402
+
+CONFIG_ID = 3
+N_DIGITS = 4
+UTTS_PER_GPU = 10000
+BETWEEN = -100
+D = 39
+FP64_MATRIX_PEAK_TFLOPS = 78.6       # MI355X dense FP64 matrix (= vector) peak, AMD datasheet
+CPU_SAMPLE = 48
+POOL = 16
+
+
+def _gen(args):
+    return synthetic.batch(*args)
+
+
+def generate(rank: int, count: int, workers: int):
+    chunk = 250
+    jobs = [(CONFIG_ID, min(chunk, count - s), N_DIGITS, rank * UTTS_PER_GPU + s) for s in range(0, count, chunk)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        parts = pool.map(_gen, jobs)
+    return [s for p in parts for s in p[0]], [d for p in parts for d in p[1]]
+
+
+# ---- CPU baseline: the oracle with the reference's loop structure, fanned out per label -------------
+def _cpu_predict(model_arrays, item):
+    """One pool task = one digit string and its clips, as scripts/project5_test_ndigits_with_sil.py:18-42."""
+    from oracle import hmm_oracle as O
+    from oracle import mfcc_oracle as M
+
+    label, signals = item
+    words = [O.WordModelRef(lab, *model_arrays[lab]) for lab in synthetic.LOOP_ORDER]
+    ltp, gauss, bounds = O.stack_models(words)
+    out = []
+    t_mfcc = t_dec = 0.0
+    for s in signals:
+        t0 = time.perf_counter()
+        x = M.mfcc_features(s).T
+        t1 = time.perf_counter()
+        _, path = O.viterbi_loop_ref(x, ltp, gauss, bounds, BETWEEN)
+        t2 = time.perf_counter()
+        out.append("".join(bounds.get_labels(path)))
+        t_mfcc += t1 - t0
+        t_dec += t2 - t1
+    return label, out, t_mfcc, t_dec
+
+
+def cpu_baseline(signals, truth, workers: int):
+    arrays = synthetic.load_word_arrays()
+    labeled = synthetic.group_by_label(signals, truth)
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(workers) as pool:
+        res = pool.map(functools.partial(_cpu_predict, arrays), list(labeled.items()))
+    wall = time.perf_counter() - t0
+    decoded = {}
+    for label, out, _, _ in res:
+        decoded[label] = out
+    cpu_s = sum(r[2] + r[3] for r in res)
+    return {"value": len(signals) / wall, "unit": "utterances/s", "cores": workers, "kind": "port",
+            "sample": f"{len(signals)} of the workload's four-digit clips, oracle with the reference's per-(frame,state) "
+                      f"SciPy logpdf loop, one pool task per digit string on {workers} processes; "
+                      f"{cpu_s / len(signals):.3f} CPU-s per utterance ({sum(r[2] for r in res) / len(signals) * 1e3:.1f} ms MFCC)",
+            "per_core": len(signals) / cpu_s}, decoded, labeled
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--utts", type=int, default=UTTS_PER_GPU, help="utterances per GPU (default: the config-3 size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    workers = max(1, POOL // max(1, min(world, 8))) if world > 1 else POOL
+
+    # host-side work that forks happens before this process touches the GPU
+    sigs, truth = generate(rank, args.utts, workers)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, cpu_decoded, cpu_labeled = cpu_baseline(sigs[:CPU_SAMPLE], truth[:CPU_SAMPLE], POOL)
+
+    import torch
+    import torch.distributed as dist
+
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, _native
+
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    eng = _native.get_engine()
+    models = synthetic.load_word_models()
+    inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
+    inf._log_transition_probability_between_words = BETWEEN
+    inf._bind()
+
+    t0 = time.perf_counter()
+    ab = eng.audio_batch(sigs)
+    torch.cuda.synchronize()
+    upload_s = time.perf_counter() - t0
+    label_cap = 16
+    out = (eng.empty((ab.n,), torch.float32), None, eng.empty((ab.n, label_cap), torch.uint8),
+           eng.empty((ab.n,), torch.int32))
+    gathered = torch.empty((world, ab.n, label_cap), dtype=torch.uint8, device=eng.device) if world > 1 else None
+
+    def step():
+        eng.recognize(ab, want_paths=False, label_cap=label_cap, out=out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out[2])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # results of the last step: strings, accuracy vs the generating strings and vs the CPU path
+    names = inf._model_boundaries._labels
+    lab = out[2].cpu().numpy()
+    cnt = out[3].cpu().numpy()
+    strings = ["".join(names[w] for w in lab[i, :min(int(cnt[i]), label_cap)]) for i in range(ab.n)]
+    acc_truth = float(np.mean([a == b for a, b in zip(strings, truth)]))
+
+    if rank == 0:
+        kernels = {}
+        for k in ("frame_index", "mel_power", "mfcc_finish", "emission", "viterbi"):
+            ms, n = eng.profile_get(k)
+            kernels[k] = {"ms_per_launch": ms / max(n, 1), "launches": n}
+        total_frames = ab.total_frames
+        S = 58
+        flops = float(S) * total_frames * (2 * D * D + 3 * D)        # algorithmic flops of one emission launch
+        em_s = kernels["emission"]["ms_per_launch"] * 1e-3
+        achieved = flops / em_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "emission_traffic.json")
+        if os.path.exists(tpath) and args.utts == UTTS_PER_GPU:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "utterances/sec (whole node), 4-digit connected-digit decode (MFCC + 58-state loop Viterbi)",
+            "value": world * ab.n * args.steps / elapsed,
+            "unit": "utterances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"config 3: {ab.n} synthetic four-digit 16 kHz clips per GPU, S=58 loop decode, between=-100",
+                       "utterances_per_gpu": ab.n, "frames_per_gpu": int(total_frames),
+                       "audio_mb_per_gpu": round(float(ab.n_samples.sum()) * 4 / 1e6, 1),
+                       "parallelism": f"utterance-sharded x{world}" + (", all-gather of label records" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "kernel": "lsr_emission_kernel", "achieved": achieved,
+                         "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
+                         "traffic": traffic, "flops_per_launch": flops, "ms_per_launch": em_s * 1e3},
+            "kernels_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in kernels.items()},
+            "seq_accuracy_vs_truth": acc_truth,
+            "h2d_upload_s": round(upload_s, 4),
+            "value_including_h2d": world * ab.n / (elapsed / args.steps + upload_s),
+        }
+        if cpu is not None:
+            # strings of the CPU sample, matched by position within each label group
+            seen = {}
+            agree = 0
+            for i in range(CPU_SAMPLE):
+                k = seen.get(truth[i], 0)
+                seen[truth[i]] = k + 1
+                agree += strings[i] == cpu_decoded[truth[i]][k]
+            line["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            line["cpu_baseline"]["per_core_utterances_per_s"] = cpu["per_core"]
+            line["strings_equal_to_cpu_path"] = f"{agree}/{CPU_SAMPLE}"
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

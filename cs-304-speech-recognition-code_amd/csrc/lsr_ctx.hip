@@ -287,17 +287,22 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     const int D = LSR_DIM;
     std::vector<double> frag((size_t)n_states * LSR_KSTEPS * LSR_JTILES * 64, 0.0);
     std::vector<double> mu((size_t)n_states * LSR_KPAD, 0.0);
+    bool triangular = true;          // zero above the diagonal: feature k only feeds components j <= k
     for (int s = 0; s < n_states; ++s) {
         for (int k = 0; k < D; ++k) mu[(size_t)s * LSR_KPAD + k] = mean[(size_t)s * D + k];
-        for (int ks = 0; ks < LSR_KSTEPS; ++ks)
-            for (int a = 0; a < LSR_JTILES; ++a)
+        for (int k = 0; k < D; ++k)
+            for (int j = k + 1; j < D; ++j)
+                if (whiten[((size_t)s * D + k) * D + j] != 0.0) triangular = false;
+        for (int a = 0; a < LSR_JTILES; ++a)
+            for (int ks = 0; ks < LSR_KSTEPS; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int k = 4 * ks + (lane >> 4), j = 16 * a + (lane & 15);
                     if (k < D && j < D)
-                        frag[(((size_t)s * LSR_KSTEPS + ks) * LSR_JTILES + a) * 64 + lane] =
+                        frag[(((size_t)s * LSR_JTILES + a) * LSR_KSTEPS + ks) * 64 + lane] =
                             whiten[((size_t)s * D + k) * D + j];
                 }
     }
+    ctx->whiten_triangular = triangular;
     int rc;
     if ((rc = upload(ctx, &ctx->d_wfrag, frag.data(), frag.size(), "whitening fragments"))) return rc;
     if ((rc = upload(ctx, &ctx->d_mean, mu.data(), mu.size(), "means"))) return rc;

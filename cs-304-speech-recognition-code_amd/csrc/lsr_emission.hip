@@ -3,18 +3,24 @@
 //   ll[f][s] = float32( -0.5 * (log_norm[s] + sum_j ( sum_k (x[f][k] - mean[s][k]) * U[s][k][j] )^2 ) )
 //
 // One wavefront owns 64 consecutive frames (4 column tiles of 16 frames) and walks over all
-// states.  Per state it issues 10 k-steps x 3 row tiles x 4 frame tiles of
-// v_mfma_f64_16x16x4_f64 with A = U_s^T fragments (read once per wave, coalesced, from the
-// pre-swizzled table built by lsr_model_upload) and B = (x - mean_s) formed in registers.
-// The 12 accumulators of a state are squared and summed in-lane, then reduced across the
-// four 16-lane groups so that lane l ends up with the score of frame l.
+// states.  A state is three row tiles of 16 whitened components; a row tile is k-steps
+// ks_begin[a]..9 of v_mfma_f64_16x16x4_f64 for each of the 4 frame tiles, with
+// A = U_s^T fragments (coalesced 512-byte loads from the pre-swizzled table built by
+// lsr_model_upload, fetched one row tile ahead of their use) and B = (x - mean_s) formed in
+// registers.  The accumulators of a row tile are squared and summed in-lane; after the third
+// tile the four 16-lane groups (rows of the C tiles) are folded so that lane l holds the score
+// of frame l, which goes to an LDS tile and from there to memory in 256-byte rows.
+//
+// ks_begin lets a lower-triangular whitening matrix (zero above the diagonal) skip the
+// all-zero k-steps of the second and third row tile; a dense matrix uses 0, 0, 0.
 #include "lsr_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define EM_WAVES 4
 
-__global__ __launch_bounds__(64 * EM_WAVES) void lsr_emission_kernel(
+template <int KB1, int KB2>
+__global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
     const double* __restrict__ mean, const double* __restrict__ lognorm, int n_states,
     float* __restrict__ ll) {
@@ -40,36 +46,59 @@ __global__ __launch_bounds__(64 * EM_WAVES) void lsr_emission_kernel(
     }
 
     const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
+    const double* wf = wfrag + lane;          // [state][row tile][k-step][lane]
+    const double* mu = mean + grp;            // [state][40]
+
+    double wc[LSR_KSTEPS], wn[LSR_KSTEPS], m[LSR_KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
+        wc[ks] = wf[ks * 64];
+        m[ks] = mu[4 * ks];
+    }
+
     for (int s = 0; s < n_states; ++s) {
-        v4d acc[LSR_JTILES][4];
+        double ss[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int a = 0; a < LSR_JTILES; ++a)
+        for (int a = 0; a < LSR_JTILES; ++a) {
+            const int kb = a == 0 ? 0 : (a == 1 ? KB1 : KB2);
+            // fetch the fragments of the next row tile (next state after the third tile)
+            {
+                const int64_t nxt = (int64_t)s * LSR_JTILES + a + 1;
+                const bool more = nxt < (int64_t)n_states * LSR_JTILES;
+                const double* src = wf + (more ? nxt : 0) * (LSR_KSTEPS * 64);
+                const int nkb = a == 0 ? KB1 : (a == 1 ? KB2 : 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[a][q] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const double* wf = wfrag + (size_t)s * (LSR_KSTEPS * LSR_JTILES * 64) + lane;
-        const double* mu = mean + (size_t)s * LSR_KPAD + grp;
-#pragma unroll
-        for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
-            const double m = mu[4 * ks];
-            const double d0 = x[0][ks] - m, d1 = x[1][ks] - m, d2 = x[2][ks] - m, d3 = x[3][ks] - m;
-#pragma unroll
-            for (int a = 0; a < LSR_JTILES; ++a) {
-                const double w = wf[(ks * LSR_JTILES + a) * 64];
-                acc[a][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, d0, acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, d1, acc[a][1], 0, 0, 0);
-                acc[a][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, d2, acc[a][2], 0, 0, 0);
-                acc[a][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, d3, acc[a][3], 0, 0, 0);
+                for (int ks = 0; ks < LSR_KSTEPS; ++ks)
+                    if (ks >= nkb) wn[ks] = src[ks * 64];
             }
+            v4d acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
+                if (ks >= kb) {
+                    const double w = wc[ks];
+                    // the differences are re-formed for every row tile (three adds are cheaper than
+                    // 80 live registers); the empty asm keeps the compiler from hoisting them
+                    double mk = m[ks];
+                    asm volatile("" : "+v"(mk));
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[0][ks] - mk, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[1][ks] - mk, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[2][ks] - mk, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[3][ks] - mk, acc[3], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss[q] = fma(acc[q][r], acc[q][r], ss[q]);
+#pragma unroll
+            for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = wn[ks];
         }
-        double ss[4];
+        const double ln = lognorm[s];
+        if (s + 1 < n_states) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double t = 0.0;
-#pragma unroll
-            for (int a = 0; a < LSR_JTILES; ++a)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t = fma(acc[a][q][r], acc[a][q][r], t);
-            ss[q] = t;
+            for (int ks = 0; ks < LSR_KSTEPS; ++ks) m[ks] = mu[(size_t)(s + 1) * LSR_KPAD + 4 * ks];
         }
         // fold the four lane groups (rows of the C tiles) so that group g keeps frame tile g
         const double keep_a = hi32 ? ss[2] : ss[0], send_a = hi32 ? ss[0] : ss[2];
@@ -78,14 +107,15 @@ __global__ __launch_bounds__(64 * EM_WAVES) void lsr_emission_kernel(
         const double v1 = keep_b + __shfl_xor(send_b, 32);
         const double keep = hi16 ? v1 : v0, send = hi16 ? v0 : v1;
         const double maha = keep + __shfl_xor(send, 16);
-        tile[wave][lane][(s ^ lane) & 63] = (float)(-0.5 * (lognorm[s] + maha));
+        tile[wave][lane][(s ^ lane) & 63] = (float)(-0.5 * (ln + maha));
     }
     __syncthreads();
     // coalesced write-out: each wave stores its own 64 x 64 tile, one 256-byte row per instruction
+    const int64_t rows = (total_frames + 63) / 64 * 64;
     for (int r = 0; r < 64; ++r) {
         const int64_t f = f0 + r;
         const float v = lane < n_states ? tile[wave][r][(lane ^ r) & 63] : -INFINITY;
-        if (f < (total_frames + 63) / 64 * 64) ll[f * LSR_LL_STRIDE + lane] = v;
+        if (f < rows) ll[f * LSR_LL_STRIDE + lane] = v;
     }
 }
 
@@ -93,8 +123,12 @@ int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames
     const int64_t per_block = 64 * EM_WAVES;
     const int64_t blocks = (total_frames + per_block - 1) / per_block;
     lsr_prof_begin(ctx, LSR_K_EMISSION);
-    hipLaunchKernelGGL(lsr_emission_kernel, dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream, feats_d,
-                       total_frames, ctx->d_wfrag, ctx->d_mean, ctx->d_lognorm, ctx->n_states, ll_d);
+    if (ctx->whiten_triangular)
+        hipLaunchKernelGGL((lsr_emission_kernel<4, 8>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
+                           feats_d, total_frames, ctx->d_wfrag, ctx->d_mean, ctx->d_lognorm, ctx->n_states, ll_d);
+    else
+        hipLaunchKernelGGL((lsr_emission_kernel<0, 0>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
+                           feats_d, total_frames, ctx->d_wfrag, ctx->d_mean, ctx->d_lognorm, ctx->n_states, ll_d);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_emission_kernel");
     return LSR_OK;

@@ -34,7 +34,8 @@ struct lsr_ctx {
 
     // model (device)
     int n_states = 0;
-    double* d_wfrag = nullptr;       // [S][10][3][64]  MFMA A-operand fragments of U^T
+    double* d_wfrag = nullptr;       // [S][3][10][64]  MFMA A-operand fragments of U^T
+    bool whiten_triangular = false;  // every whitening matrix is zero above the diagonal
     double* d_mean = nullptr;        // [S][40]
     double* d_lognorm = nullptr;     // [S]
 

@@ -228,11 +228,21 @@ class Engine:
         return FeatureBatch(out, batch.frame_off, batch.lengths)
 
     # -- model / graph ----------------------------------------------------------------------------
-    def set_model(self, token, mean: np.ndarray, whiten: np.ndarray, log_norm: np.ndarray) -> None:
+    def set_model(self, token, mean: np.ndarray, whiten: np.ndarray, log_norm: np.ndarray,
+                  triangular: Optional[bool] = None) -> None:
+        """Upload stacked Gaussians.  By default the whitening matrices are first rotated to lower
+        triangular form: U^T = Q R gives L = R^T with L L^T = U U^T, so |(x - mu) L|^2 is the same
+        Mahalanobis distance (an orthogonal change of basis of the whitened vector) while the
+        device skips the k-steps that are structurally zero (18 instead of 30 MFMA groups per
+        state).  ``triangular=False`` (or LSR_DENSE_WHITEN=1) uploads SciPy's U unchanged."""
         if token is not None and token == self._model_token:
             return
+        if triangular is None:
+            triangular = os.environ.get("LSR_DENSE_WHITEN", "0") != "1"
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         whiten = np.ascontiguousarray(whiten, dtype=np.float64)
+        if triangular:
+            whiten = np.stack([np.tril(np.linalg.qr(u.T)[1].T) for u in whiten])
         log_norm = np.ascontiguousarray(log_norm, dtype=np.float64)
         S = mean.shape[0]
         assert mean.shape == (S, DIM) and whiten.shape == (S, DIM, DIM) and log_norm.shape == (S,)

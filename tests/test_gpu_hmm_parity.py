@@ -19,13 +19,14 @@ def test_g1_emission():
     assert np.array_equal(np.stack([m.whiten for m in mvn[:4]]), g["U_first4"])
     assert np.array_equal(np.array([m.log_pdet for m in mvn]), g["logdet"])
     eng = _native.get_engine()
-    eng.set_model(None, *stack_gaussians(mvn))
-    ll = eng.emission(eng.feature_batch([g["x"]])).cpu().numpy()
-    got, ref = ll[:64, :58], g["ll"]
-    assert rel_err(got, ref) <= 1e-4
-    assert np.all(np.abs(got - ref) <= np.spacing(np.abs(ref)))
-    assert np.mean(got != ref) < 2e-3
-    assert np.all(np.isneginf(ll[:64, 58:]))
+    for triangular in (False, True):          # SciPy's U as is / rotated to lower triangular form
+        eng.set_model(None, *stack_gaussians(mvn), triangular=triangular)
+        ll = eng.emission(eng.feature_batch([g["x"]])).cpu().numpy()
+        got, ref = ll[:64, :58], g["ll"]
+        assert rel_err(got, ref) <= 1e-4
+        assert np.all(np.abs(got - ref) <= np.spacing(np.abs(ref)))
+        assert np.mean(got != ref) < 2e-3
+        assert np.all(np.isneginf(ll[:64, 58:]))
     # single-vector interface (hidden_markov_model.py:46-48)
     v = mvn[7].log_pdf(g["x"][3])
     assert v.dtype == np.float32 and abs(v - ref[3, 7]) <= np.spacing(abs(ref[3, 7]))
