@@ -169,7 +169,8 @@ static int upload(lsr_ctx* ctx, T** dst, const T* src, size_t n, const char* wha
 int lsr_frontend_init(lsr_ctx* ctx) {
     std::vector<double> win(LSR_N_FFT), tw160(16 * 10 * 2), tw320(LSR_N_BINS * 2), dct(LSR_N_MFCC * LSR_N_MELS);
     std::vector<float> melw(LSR_N_MELS * LSR_N_BINS);
-    std::vector<int> lo(LSR_N_MELS), hi(LSR_N_MELS);
+    std::vector<float> slot_w(64 * 6, 0.f);
+    std::vector<int> slot_info(64, 0), band_slots(LSR_N_MELS * 2, 0);
     lsr_host_hann_window(win.data());
     lsr_host_mel_filterbank(melw.data());
     lsr_host_dct_matrix(dct.data());
@@ -184,6 +185,9 @@ int lsr_frontend_init(lsr_ctx* ctx) {
         tw320[k * 2 + 0] = cos(ang);
         tw320[k * 2 + 1] = sin(ang);
     }
+    // The non-zero weights of a band are one run of consecutive bins; cut every run into slots of
+    // at most 6 bins.  The kernel gives one lane to each slot, so there must be at most 64.
+    int n_slots = 0;
     for (int b = 0; b < LSR_N_MELS; ++b) {
         int first = LSR_N_BINS, last = 0;
         for (int k = 0; k < LSR_N_BINS; ++k)
@@ -192,16 +196,25 @@ int lsr_frontend_init(lsr_ctx* ctx) {
                 last = k + 1;
             }
         if (first > last) first = last = 0;
-        lo[b] = first;
-        hi[b] = last;
+        band_slots[2 * b] = n_slots;
+        for (int k0 = first; k0 < last; k0 += 6) {
+            if (n_slots >= 64) return lsr_fail(ctx, LSR_ERR_LIMIT, "mel filterbank needs more than 64 slots");
+            int start = k0;
+            if (start + 6 > LSR_N_BINS) start = LSR_N_BINS - 6;      // keep the 6-bin read inside the spectrum
+            slot_info[n_slots] = start;
+            for (int k = k0; k < last && k < k0 + 6; ++k) slot_w[n_slots * 6 + (k - start)] = melw[b * LSR_N_BINS + k];
+            ++n_slots;
+        }
+        band_slots[2 * b + 1] = n_slots - band_slots[2 * b];
+        if (band_slots[2 * b + 1] == 0) return lsr_fail(ctx, LSR_ERR_LIMIT, "empty mel band");
     }
     int rc;
     if ((rc = upload(ctx, &ctx->d_window, win.data(), win.size(), "window"))) return rc;
     if ((rc = upload(ctx, &ctx->d_tw160, tw160.data(), tw160.size(), "twiddles"))) return rc;
     if ((rc = upload(ctx, &ctx->d_tw320, tw320.data(), tw320.size(), "twiddles"))) return rc;
-    if ((rc = upload(ctx, &ctx->d_melw, melw.data(), melw.size(), "mel weights"))) return rc;
-    if ((rc = upload(ctx, &ctx->d_mel_lo, lo.data(), lo.size(), "mel ranges"))) return rc;
-    if ((rc = upload(ctx, &ctx->d_mel_hi, hi.data(), hi.size(), "mel ranges"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_slot_w, slot_w.data(), slot_w.size(), "mel slot weights"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_slot_info, slot_info.data(), slot_info.size(), "mel slots"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_band_slots, band_slots.data(), band_slots.size(), "mel bands"))) return rc;
     if ((rc = upload(ctx, &ctx->d_dct, dct.data(), dct.size(), "dct matrix"))) return rc;
     return LSR_OK;
 }
@@ -214,9 +227,9 @@ void lsr_frontend_free(lsr_ctx* ctx) {
     free_ptr(ctx->d_window);
     free_ptr(ctx->d_tw160);
     free_ptr(ctx->d_tw320);
-    free_ptr(ctx->d_melw);
-    free_ptr(ctx->d_mel_lo);
-    free_ptr(ctx->d_mel_hi);
+    free_ptr(ctx->d_slot_w);
+    free_ptr(ctx->d_slot_info);
+    free_ptr(ctx->d_band_slots);
     free_ptr(ctx->d_dct);
 }
 

@@ -27,9 +27,9 @@ struct lsr_ctx {
     double* d_window = nullptr;      // [320]
     double* d_tw160 = nullptr;       // [16][10][2]  W160^(n2*k1)
     double* d_tw320 = nullptr;       // [161][2]     W320^k
-    float* d_melw = nullptr;         // [40][161]
-    int* d_mel_lo = nullptr;         // [40] first non-zero bin
-    int* d_mel_hi = nullptr;         // [40] one past the last non-zero bin
+    float* d_slot_w = nullptr;       // [64][6] mel weights of each slot (a run of <= 6 bins of one band)
+    int* d_slot_info = nullptr;      // [64] first bin of each slot
+    int* d_band_slots = nullptr;     // [40][2] first slot and slot count of each band
     double* d_dct = nullptr;         // [13][40]
 
     // model (device)

@@ -23,7 +23,7 @@ struct cplx {
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
-    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+    return {fma(a.re, b.re, -(a.im * b.im)), fma(a.re, b.im, a.im * b.re)};
 }
 __device__ __forceinline__ cplx cmul_negi(cplx a) { return {a.im, -a.re}; }   // a * (-i)
 __device__ __forceinline__ cplx cmul_posi(cplx a) { return {-a.im, a.re}; }   // a * (+i)
@@ -60,139 +60,200 @@ __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, in
     for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) frame_utt[f] = b;
 }
 
-#define MP_FRAMES 16
+#define MP_FRAMES 4          // frames per wavefront pass
 #define MP_YLD 17            // complex elements per (frame, k1) row: 16 + 1 pad
 #define MP_ZLD 161
 #define MP_PLD 164
+#define MP_SLOT_BINS 6       // bins per mel slot (61 slots cover the 260 non-zero weights)
 
-__global__ __launch_bounds__(256) void lsr_mel_power_kernel(
-    const float* __restrict__ audio, const int64_t* __restrict__ sample_off, const int64_t* __restrict__ frame_off,
-    const int32_t* __restrict__ frame_utt, int64_t total_frames, const double* __restrict__ window,
-    const double* __restrict__ tw160, const double* __restrict__ tw320, const float* __restrict__ melw,
-    const int* __restrict__ mel_lo, const int* __restrict__ mel_hi, float* __restrict__ mel,
-    unsigned int* __restrict__ uttmax) {
-    __shared__ __attribute__((aligned(16))) cplx buf[MP_FRAMES * 10 * MP_YLD];   // Y, then reused as Z [16][161]
-    __shared__ float power[MP_FRAMES][MP_PLD];
-    __shared__ unsigned int fmax_bits[MP_FRAMES];
-    __shared__ int utt_of[MP_FRAMES];
-
-    const int tid = threadIdx.x;
-    const int64_t g0 = (int64_t)blockIdx.x * MP_FRAMES;
-    if (tid < MP_FRAMES) {
-        fmax_bits[tid] = 0u;
-        utt_of[tid] = (g0 + tid < total_frames) ? frame_utt[g0 + tid] : -1;
-    }
-
-    // ---- stage A: 10-point DFTs over n1 for fixed (frame, n2) --------------------------------
-    {
-        const int f = tid >> 4, n2 = tid & 15;
-        const int64_t g = g0 + f;
-        cplx z[10];
-        if (g < total_frames) {
-            const int b = frame_utt[g];
-            const int64_t s0 = sample_off[b];
-            const int64_t ns = sample_off[b + 1] - s0;
-            const int64_t first = (int64_t)LSR_HOP * (g - frame_off[b]) - LSR_N_FFT / 2;   // centre padding
-            const float* sig = audio + s0;
+// samples 2m, 2m+1 (m = 16 n1 + n2, n1 = 0..9) of frame `g` for one lane; zero outside the clip
+__device__ __forceinline__ void mp_load_samples(const float* __restrict__ audio, const int64_t* __restrict__ sample_off,
+                                                const int64_t* __restrict__ frame_off,
+                                                const int32_t* __restrict__ frame_utt, int64_t total_frames, int64_t g,
+                                                int n2, float (&xs)[20]) {
+    if (g < total_frames) {
+        const int b = frame_utt[g];
+        const int64_t s0 = sample_off[b];
+        const int64_t ns = sample_off[b + 1] - s0;
+        const int64_t first = (int64_t)LSR_HOP * (g - frame_off[b]) - LSR_N_FFT / 2;   // centre padding
+        const float* sig = audio + s0 + first + 2 * n2;
+        if (first >= 0 && first + LSR_N_FFT <= ns) {
 #pragma unroll
             for (int n1 = 0; n1 < 10; ++n1) {
-                const int j = 2 * (16 * n1 + n2);
-                const int64_t i0 = first + j, i1 = i0 + 1;
-                const double x0 = (i0 >= 0 && i0 < ns) ? (double)sig[i0] : 0.0;
-                const double x1 = (i1 >= 0 && i1 < ns) ? (double)sig[i1] : 0.0;
-                z[n1] = {window[j] * x0, window[j + 1] * x1};
+                xs[2 * n1] = sig[32 * n1];
+                xs[2 * n1 + 1] = sig[32 * n1 + 1];
             }
         } else {
 #pragma unroll
-            for (int n1 = 0; n1 < 10; ++n1) z[n1] = {0.0, 0.0};
-        }
-        cplx E[5], O[5];
-        dft5(z[0], z[2], z[4], z[6], z[8], E);
-        dft5(z[1], z[3], z[5], z[7], z[9], O);
-        // W10^k, k = 0..4
-        const double wc[5] = {1.0, 0.80901699437494742410, 0.30901699437494742410, -0.30901699437494742410,
-                              -0.80901699437494742410};
-        const double wsn[5] = {0.0, -0.58778525229247312917, -0.95105651629515357212, -0.95105651629515357212,
-                               -0.58778525229247312917};
-        const double* tw = tw160 + n2 * 20;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const cplx wo = cmul(O[k], cplx{wc[k], wsn[k]});
-            const cplx lo = cadd(E[k], wo), hi = csub(E[k], wo);
-            buf[(f * 10 + k) * MP_YLD + n2] = cmul(lo, cplx{tw[2 * k], tw[2 * k + 1]});
-            buf[(f * 10 + k + 5) * MP_YLD + n2] = cmul(hi, cplx{tw[2 * (k + 5)], tw[2 * (k + 5) + 1]});
-        }
-    }
-    __syncthreads();
-
-    // ---- stage B: 16-point DFTs over n2 for fixed (frame, k1) ---------------------------------
-    {
-        cplx y[16], X[16];
-        const bool live = tid < MP_FRAMES * 10;
-        if (live) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) y[i] = buf[tid * MP_YLD + i];
-        }
-        __syncthreads();                     // every Y row is in registers: the buffer becomes Z
-        if (live) {
-            const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178;   // cos, sin(pi/8)
-            const double R = 0.70710678118654752440;
-            // W16^m = (cos(pi m/8), -sin(pi m/8)) for m = 0,1,2,3,4,6,9
-            const cplx w1 = {C1, -S1}, w2 = {R, -R}, w3 = {S1, -C1}, w4 = {0.0, -1.0}, w6 = {-R, -R}, w9 = {-C1, S1};
-            cplx u[4][4];                    // u[n2][k1] = DFT4 over n1 of y[4 n1 + n2]
-#pragma unroll
-            for (int n2 = 0; n2 < 4; ++n2) dft4(y[n2], y[4 + n2], y[8 + n2], y[12 + n2], u[n2]);
-            u[1][1] = cmul(u[1][1], w1);
-            u[1][2] = cmul(u[1][2], w2);
-            u[1][3] = cmul(u[1][3], w3);
-            u[2][1] = cmul(u[2][1], w2);
-            u[2][2] = cmul(u[2][2], w4);
-            u[2][3] = cmul(u[2][3], w6);
-            u[3][1] = cmul(u[3][1], w3);
-            u[3][2] = cmul(u[3][2], w6);
-            u[3][3] = cmul(u[3][3], w9);
-#pragma unroll
-            for (int k1 = 0; k1 < 4; ++k1) {
-                cplx o[4];
-                dft4(u[0][k1], u[1][k1], u[2][k1], u[3][k1], o);
-#pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2) X[k1 + 4 * k2] = o[k2];
+            for (int n1 = 0; n1 < 10; ++n1) {
+                const int64_t i0 = first + 2 * n2 + 32 * n1, i1 = i0 + 1;
+                xs[2 * n1] = (i0 >= 0 && i0 < ns) ? sig[32 * n1] : 0.f;
+                xs[2 * n1 + 1] = (i1 >= 0 && i1 < ns) ? sig[32 * n1 + 1] : 0.f;
             }
-            const int f = tid / 10, k1 = tid % 10;
+        }
+    } else {
 #pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) buf[f * MP_ZLD + k1 + 10 * k2] = X[k2];
-        }
+        for (int i = 0; i < 20; ++i) xs[i] = 0.f;
     }
+}
+
+// |X|^2 of the spectrum rounded to complex64.  NumPy squares the float32 magnitude
+// (hypotf); re*re + im*im in float32 agrees with that to 2 ulp, far inside the tolerance of
+// the dB / DCT chain that follows, and needs no square root.
+__device__ __forceinline__ float mp_power(double re64, double im64) {
+    const float re = (float)re64, im = (float)im64;
+    return fmaf(re, re, im * im);
+}
+
+// untangle one bin pair (k, 160-k) of a frame from the half-size transform Z:
+// Z = Xe + i Xo (spectra of the even/odd samples), Xe = (Z[k] + conj Z[160-k]) / 2,
+// Xo = -i (Z[k] - conj Z[160-k]) / 2, X[k] = Xe + W320^k Xo, X[160-k] = conj(Xe - W320^k Xo)
+__device__ __forceinline__ void mp_untangle(const cplx* __restrict__ z, float* __restrict__ pw, int k, cplx w) {
+    const cplx zk = z[k];
+    const cplx zm = z[k == 0 ? 0 : 160 - k];
+    const cplx e = {0.5 * (zk.re + zm.re), 0.5 * (zk.im - zm.im)};
+    const cplx d = {0.5 * (zk.re - zm.re), 0.5 * (zk.im + zm.im)};
+    const cplx t = cmul(cmul_negi(d), w);
+    pw[k] = mp_power(e.re + t.re, e.im + t.im);
+    if (k != 80) pw[160 - k] = mp_power(e.re - t.re, e.im - t.im);
+}
+
+__global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
+    const float* __restrict__ audio, const int64_t* __restrict__ sample_off, const int64_t* __restrict__ frame_off,
+    const int32_t* __restrict__ frame_utt, int64_t total_frames, int64_t n_groups, const double* __restrict__ window,
+    const double* __restrict__ tw160, const double* __restrict__ tw320, const float* __restrict__ slot_w,
+    const int* __restrict__ slot_info, const int* __restrict__ band_slots, float* __restrict__ mel,
+    unsigned int* __restrict__ uttmax) {
+    __shared__ __attribute__((aligned(16))) cplx buf[MP_FRAMES * 10 * MP_YLD];   // Y, then reused as Z [4][161]
+    __shared__ float power[MP_FRAMES][MP_PLD];
+    __shared__ float part[MP_FRAMES][64];
+    __shared__ unsigned int fmax_bits[MP_FRAMES];
+    __shared__ __attribute__((aligned(16))) cplx win_s[160];     // window pairs (w[2m], w[2m+1])
+    __shared__ __attribute__((aligned(16))) cplx tw_s[10 * 16];  // W160^(n2 k1) as [k1][n2]
+
+    const int lane = threadIdx.x;
+    const int f = lane >> 4, n2 = lane & 15;
+
+    // tables of the first two stages live in LDS (read as 16-byte pairs, one bank row per 16 lanes)
+    for (int i = lane; i < 160; i += 64) {
+        win_s[i] = {window[2 * i], window[2 * i + 1]};
+        const int k1 = i >> 4, m = i & 15;
+        tw_s[i] = {tw160[m * 20 + 2 * k1], tw160[m * 20 + 2 * k1 + 1]};
+    }
+    // per-lane constants kept in registers across the grid-stride loop
+    const cplx tw_a = {tw320[2 * lane], tw320[2 * lane + 1]};                          // bin pair k = lane
+    const cplx tw_b = {tw320[2 * (64 + n2)], tw320[2 * (64 + n2) + 1]};                // bin pair k = 64 + (lane & 15)
+    const cplx tw_c = {tw320[160], tw320[161]};                                        // bin 80
+    // mel filterbank slot of this lane: up to MP_SLOT_BINS consecutive bins of one band
+    float sw[MP_SLOT_BINS];
+#pragma unroll
+    for (int j = 0; j < MP_SLOT_BINS; ++j) sw[j] = slot_w[lane * MP_SLOT_BINS + j];
+    const int slot_start = slot_info[lane];
+    float xs[20];
+    mp_load_samples(audio, sample_off, frame_off, frame_utt, total_frames, (int64_t)blockIdx.x * MP_FRAMES + f, n2, xs);
     __syncthreads();
 
-    // ---- stage C: untangle the real spectrum, magnitude and power in float32 -------------------
-    for (int i = tid; i < MP_FRAMES * LSR_N_BINS; i += 256) {
-        const int f = i / LSR_N_BINS, k = i % LSR_N_BINS;
-        const cplx zk = buf[f * MP_ZLD + (k == 160 ? 0 : k)];
-        const cplx zm = buf[f * MP_ZLD + (k == 0 ? 0 : 160 - k)];
-        const cplx e = {0.5 * (zk.re + zm.re), 0.5 * (zk.im - zm.im)};
-        const cplx d = {0.5 * (zk.re - zm.re), 0.5 * (zk.im + zm.im)};
-        const cplx x = cadd(e, cmul(cmul_negi(d), cplx{tw320[2 * k], tw320[2 * k + 1]}));
-        const float re = (float)x.re, im = (float)x.im;
-        const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);
-        power[f][k] = mag * mag;
-    }
-    __syncthreads();
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t g0 = grp * MP_FRAMES;
+        if (lane < MP_FRAMES) fmax_bits[lane] = 0u;
 
-    // ---- stage D: mel filterbank (float64 accumulate, rounded to float32) + utterance maximum ----
-    for (int i = tid; i < MP_FRAMES * LSR_N_MELS; i += 256) {
-        const int f = i / LSR_N_MELS, band = i % LSR_N_MELS;
-        if (g0 + f < total_frames) {
-            const float* w = melw + band * LSR_N_BINS;
-            double acc = 0.0;
-            for (int k = mel_lo[band]; k < mel_hi[band]; ++k) acc = fma((double)w[k], (double)power[f][k], acc);
-            const float m = (float)acc;
-            mel[(g0 + f) * LSR_N_MELS + band] = m;
-            atomicMax(&fmax_bits[f], __float_as_uint(m));
+        // ---- stage A: 10-point DFTs over n1 for fixed (frame, n2) ------------------------------
+        {
+            cplx z[10];
+#pragma unroll
+            for (int n1 = 0; n1 < 10; ++n1) {
+                const cplx w = win_s[16 * n1 + n2];
+                z[n1] = {w.re * (double)xs[2 * n1], w.im * (double)xs[2 * n1 + 1]};
+            }
+            // the next group's samples travel while this group is transformed
+            mp_load_samples(audio, sample_off, frame_off, frame_utt, total_frames,
+                            (grp + gridDim.x) * MP_FRAMES + f, n2, xs);
+            cplx E[5], O[5];
+            dft5(z[0], z[2], z[4], z[6], z[8], E);
+            dft5(z[1], z[3], z[5], z[7], z[9], O);
+            // W10^k, k = 0..4
+            const double wc[5] = {1.0, 0.80901699437494742410, 0.30901699437494742410, -0.30901699437494742410,
+                                  -0.80901699437494742410};
+            const double wsn[5] = {0.0, -0.58778525229247312917, -0.95105651629515357212, -0.95105651629515357212,
+                                   -0.58778525229247312917};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const cplx wo = cmul(O[k], cplx{wc[k], wsn[k]});
+                buf[(f * 10 + k) * MP_YLD + n2] = cmul(cadd(E[k], wo), tw_s[16 * k + n2]);
+                buf[(f * 10 + k + 5) * MP_YLD + n2] = cmul(csub(E[k], wo), tw_s[16 * (k + 5) + n2]);
+            }
         }
+        __syncthreads();
+
+        // ---- stage B: 16-point DFTs over n2 for fixed (frame, k1) -------------------------------
+        {
+            cplx y[16];
+            const bool live = lane < MP_FRAMES * 10;
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) y[i] = buf[lane * MP_YLD + i];
+            }
+            __syncthreads();                 // every Y row is in registers: the buffer becomes Z
+            if (live) {
+                const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178;   // cos, sin(pi/8)
+                const double R = 0.70710678118654752440;
+                // W16^m = (cos(pi m/8), -sin(pi m/8)) for m = 1,2,3,4,6,9
+                const cplx w1 = {C1, -S1}, w2 = {R, -R}, w3 = {S1, -C1}, w6 = {-R, -R}, w9 = {-C1, S1};
+                cplx u[4][4];                // u[n2][k1] = DFT4 over n1 of y[4 n1 + n2]
+#pragma unroll
+                for (int m = 0; m < 4; ++m) dft4(y[m], y[4 + m], y[8 + m], y[12 + m], u[m]);
+                u[1][1] = cmul(u[1][1], w1);
+                u[1][2] = cmul(u[1][2], w2);
+                u[1][3] = cmul(u[1][3], w3);
+                u[2][1] = cmul(u[2][1], w2);
+                u[2][2] = cmul_negi(u[2][2]);          // W16^4 = -i
+                u[2][3] = cmul(u[2][3], w6);
+                u[3][1] = cmul(u[3][1], w3);
+                u[3][2] = cmul(u[3][2], w6);
+                u[3][3] = cmul(u[3][3], w9);
+                cplx* zrow = buf + (lane / 10) * MP_ZLD + lane % 10;
+#pragma unroll
+                for (int k1 = 0; k1 < 4; ++k1) {
+                    cplx o[4];
+                    dft4(u[0][k1], u[1][k1], u[2][k1], u[3][k1], o);
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) zrow[10 * (k1 + 4 * k2)] = o[k2];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- stage C: real spectrum and power; every lane keeps its twiddle factors in registers -----
+#pragma unroll
+        for (int fc = 0; fc < MP_FRAMES; ++fc) mp_untangle(buf + fc * MP_ZLD, power[fc], lane, tw_a);
+        mp_untangle(buf + f * MP_ZLD, power[f], 64 + n2, tw_b);
+        if (lane < MP_FRAMES) mp_untangle(buf + lane * MP_ZLD, power[lane], 80, tw_c);
+        __syncthreads();
+
+        // ---- stage D: mel filterbank.  Lane = slot (a run of <= 6 bins of one band, weights in
+        // registers, float32 FMA chain); then each band adds its 1-3 slot sums in slot order ----------
+#pragma unroll
+        for (int fd = 0; fd < MP_FRAMES; ++fd) {
+            const float* pw = power[fd] + slot_start;
+            float acc = sw[0] * pw[0];
+#pragma unroll
+            for (int j = 1; j < MP_SLOT_BINS; ++j) acc = fmaf(sw[j], pw[j], acc);
+            part[fd][lane] = acc;
+        }
+        __syncthreads();
+        for (int i = lane; i < MP_FRAMES * LSR_N_MELS; i += 64) {
+            const int fd = i / LSR_N_MELS, band = i % LSR_N_MELS;
+            if (g0 + fd < total_frames) {
+                const int first = band_slots[2 * band], count = band_slots[2 * band + 1];
+                float m = part[fd][first];
+                for (int j = 1; j < count; ++j) m += part[fd][first + j];
+                mel[(g0 + fd) * LSR_N_MELS + band] = m;
+                atomicMax(&fmax_bits[fd], __float_as_uint(m));
+            }
+        }
+        __syncthreads();
+        if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[frame_utt[g0 + lane]], fmax_bits[lane]);
     }
-    __syncthreads();
-    if (tid < MP_FRAMES && utt_of[tid] >= 0) atomicMax(&uttmax[utt_of[tid]], fmax_bits[tid]);
 }
 
 #define FN_FRAMES 64
@@ -306,11 +367,14 @@ int lsr_launch_mfcc(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_of
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_frame_index_kernel");
 
-    const unsigned blocks_mp = (unsigned)((total_frames + MP_FRAMES - 1) / MP_FRAMES);
+    // persistent single-wave workgroups: eight per CU (two per SIMD, 13.5 KiB of LDS each); each walks over
+    // groups of 4 frames with a grid stride
+    const int64_t n_groups = (total_frames + MP_FRAMES - 1) / MP_FRAMES;
+    const unsigned blocks_mp = (unsigned)(n_groups < 256 * 8 ? n_groups : 256 * 8);
     lsr_prof_begin(ctx, LSR_K_MEL_POWER);
-    hipLaunchKernelGGL(lsr_mel_power_kernel, dim3(blocks_mp), dim3(256), 0, ctx->stream, audio_d, sample_off_d,
-                       frame_off_d, frame_utt, total_frames, ctx->d_window, ctx->d_tw160, ctx->d_tw320, ctx->d_melw,
-                       ctx->d_mel_lo, ctx->d_mel_hi, mel, uttmax);
+    hipLaunchKernelGGL(lsr_mel_power_kernel, dim3(blocks_mp), dim3(64), 0, ctx->stream, audio_d, sample_off_d,
+                       frame_off_d, frame_utt, total_frames, n_groups, ctx->d_window, ctx->d_tw160, ctx->d_tw320,
+                       ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots, mel, uttmax);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_mel_power_kernel");
 
