@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void lsr_mfcc_finish_kernel(
             const float amin = 1e-10f;
             const float ref = __uint_as_float(uttmax[frame_utt[g]]);
             const float m = mel[g * LSR_N_MELS + band];
-            const float a = 10.0f * (float)log10((double)fmaxf(amin, m));
-            const float r = 10.0f * (float)log10((double)fmaxf(amin, ref));
+            const float a = 10.0f * log10f(fmaxf(amin, m));
+            const float r = 10.0f * log10f(fmaxf(amin, ref));
             v = fmaxf(a - r, -80.0f);
         }
         logmel[fr][band] = v;
