@@ -13,7 +13,7 @@ from .hidden_markov_model import (MultivariateNormal, HiddenMarkovModel, HiddenM
                                   HiddenMarkovModelTrainContinuous)
 from .model_collection import ModelCollection
 from .ti_digits import TI_DIGITS_LABELS
-from . import _native, synthetic
+from . import _native, distributed, synthetic
 
 __all__ = ["MFCC", "SparseMatrix", "TransitionProbabilities", "LogTransitionProbabilities", "ModelBoundary", "Signal",
            "SortedSignals", "MultivariateNormal", "HiddenMarkovModel", "HiddenMarkovModelTrainable",

@@ -18,6 +18,7 @@ import numpy as np
 import scipy.linalg
 
 from . import _native
+from .distributed import all_reduce_stats
 from .model_boundary import ModelBoundary
 from .signal import Signal, SortedSignals
 from .transition_probability import LogTransitionProbabilities, TransitionProbabilities
@@ -678,13 +679,3 @@ class HiddenMarkovModelTrainContinuous:
     @staticmethod
     def insert_silence(labels: str) -> str:
         return "".join(f"S{c}" for c in labels) + "S"
-
-
-def all_reduce_stats(stats):
-    """Sum the packed float64 statistics over all ranks (one RCCL all-reduce per training
-    iteration) when torch.distributed is initialised; identity otherwise."""
-    import torch.distributed as dist
-
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    return stats
