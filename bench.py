@@ -31,6 +31,13 @@ CONFIG_ID = 3
 N_DIGITS = 4
 UTTS_PER_GPU = 10000
 BETWEEN = -100
+# other BASELINE.json configurations, selectable with --config (the default and the driver's run is 3)
+CONFIGS = {
+    2: dict(utts=1024, digits=1, what="1 024 one-digit clips: MFCC + loop decode + isolated 11-model classification"),
+    3: dict(utts=10000, digits=4, what="10 000 four-digit clips: MFCC + S=58 loop decode, between=-100"),
+    4: dict(utts=12000, digits=[1, 2, 3, 4, 5, 7], what="one continuous-training iteration (forced alignment + statistics + M-step) over 12 000 clips of 1-7 digits"),
+    5: dict(utts=50000, digits=7, what="50 000 seven-digit clips: MFCC + S=58 loop decode, between=-100"),
+}
 D = 39
 FP64_MATRIX_PEAK_TFLOPS = 78.6       # MI355X dense FP64 matrix (= vector) peak, AMD datasheet
 CPU_SAMPLE = 48
@@ -41,9 +48,9 @@ def _gen(args):
     return synthetic.batch(*args)
 
 
-def generate(rank: int, count: int, workers: int):
-    chunk = 250
-    jobs = [(CONFIG_ID, min(chunk, count - s), N_DIGITS, rank * UTTS_PER_GPU + s) for s in range(0, count, chunk)]
+def generate(rank: int, count: int, workers: int, config_id: int = CONFIG_ID, digits=N_DIGITS):
+    chunk = 240
+    jobs = [(config_id, min(chunk, count - s), digits, rank * count + s) for s in range(0, count, chunk)]
     with mp.get_context("fork").Pool(workers) as pool:
         parts = pool.map(_gen, jobs)
     return [s for p in parts for s in p[0]], [d for p in parts for d in p[1]]
@@ -90,6 +97,100 @@ def cpu_baseline(signals, truth, workers: int):
             "per_core": len(signals) / cpu_s}, decoded, labeled
 
 
+def _setup(args):
+    """Process-group and engine set-up shared by all configurations."""
+    import torch
+    import torch.distributed as dist
+
+    from loe_speech_recognition_amd import _native
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("LSR_DIST_BACKEND", "nccl")
+    dev = local % torch.cuda.device_count()          # more ranks than GPUs only in gloo rehearsals
+    torch.cuda.set_device(dev)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    return torch, dist, _native.Engine(dev), rank, world, backend
+
+
+def other_config(args):
+    """Configs 2, 4 and 5: same timing contract, reported with their own metric names."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cfg = CONFIGS[args.config]
+    utts = args.utts if args.utts != UTTS_PER_GPU else cfg["utts"]
+    workers = max(1, POOL // max(1, min(world, 8)))
+    sigs, truth = generate(rank, utts, workers, args.config, cfg["digits"])
+    torch, dist, eng, rank, world, backend = _setup(args)
+    from loe_speech_recognition_amd import (MFCC, HiddenMarkovModelInference, HiddenMarkovModelTrainContinuous,
+                                            ModelCollection, _native)
+    _native._engine, _native._engine_pid = eng, os.getpid()
+    models = synthetic.load_word_models()
+    ab = eng.audio_batch(sigs)
+    extra = {}
+    if args.config in (2, 5):
+        inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
+        inf._log_transition_probability_between_words = BETWEEN
+        mc = ModelCollection()
+        mc._models = [models[lab] for lab in synthetic.WORDS]
+        state = {}
+
+        def step():
+            inf._bind()
+            state["out"] = eng.recognize(ab, want_paths=False, label_cap=16)
+            if args.config == 2:
+                state["iso"] = mc.predict_batch(eng.mfcc(ab))
+    else:
+        tc = HiddenMarkovModelTrainContinuous(isTqdm=False)
+        for lab in synthetic.WORDS + ["S"]:
+            tc.add_model(models[lab])
+        fb = eng.mfcc(ab)
+        labeled = {"__prepared__": None}
+        tc.__dict__["_data_cache"] = {"key": id(labeled), "fb": fb, "owner": truth}
+
+        def step():
+            tc._iteration(labeled)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if args.config in (2, 5):
+        names = inf._model_boundaries._labels
+        lab, cnt = state["out"][2].cpu().numpy(), state["out"][3].cpu().numpy()
+        strings = ["".join(names[w] for w in lab[i, :min(int(cnt[i]), 16)]) for i in range(ab.n)]
+        extra["seq_accuracy_vs_truth"] = float(np.mean([a == b for a, b in zip(strings, truth)]))
+        if args.config == 2:
+            extra["isolated_accuracy_vs_truth"] = float(np.mean([a == b for a, b in zip(state["iso"], truth)]))
+    if rank == 0:
+        print(json.dumps({"metric": f"utterances/sec, BASELINE config {args.config}", "value": world * ab.n * args.steps / elapsed,
+                          "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": cfg["what"], "utterances_per_gpu": ab.n, "frames_per_gpu": ab.total_frames},
+                          **extra}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +198,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=UTTS_PER_GPU, help="utterances per GPU (default: the config-3 size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     args = ap.parse_args()
+    if args.config != 3:
+        return other_config(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,15 +214,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, cpu_decoded, cpu_labeled = cpu_baseline(sigs[:CPU_SAMPLE], truth[:CPU_SAMPLE], POOL)
 
-    import torch
-    import torch.distributed as dist
-
     from loe_speech_recognition_amd import HiddenMarkovModelInference, _native
 
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    eng = _native.get_engine()
+    torch, dist, eng, rank, world, backend = _setup(args)
+    _native._engine, _native._engine_pid = eng, os.getpid()
     models = synthetic.load_word_models()
     inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
     inf._log_transition_probability_between_words = BETWEEN
@@ -131,12 +230,15 @@ def main():
     label_cap = 16
     out = (eng.empty((ab.n,), torch.float32), None, eng.empty((ab.n, label_cap), torch.uint8),
            eng.empty((ab.n,), torch.int32))
-    gathered = torch.empty((world, ab.n, label_cap), dtype=torch.uint8, device=eng.device) if world > 1 else None
+    gathered = torch.empty((world * ab.n, label_cap), dtype=torch.uint8, device=eng.device) if world > 1 else None
+
+    if world > 1 and backend != "nccl":                # gloo rehearsal: records travel through host memory
+        gathered = torch.empty((world * ab.n, label_cap), dtype=torch.uint8)
 
     def step():
         eng.recognize(ab, want_paths=False, label_cap=label_cap, out=out)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out[2])
+            dist.all_gather_into_tensor(gathered, out[2] if backend == "nccl" else out[2].cpu())
 
     def barrier():
         if world > 1:
@@ -155,7 +257,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
