@@ -564,34 +564,69 @@ class HiddenMarkovModelTrainContinuous:
             self.__dict__["_data_cache"] = cache
         return cache["fb"], cache["owner"]
 
+    def _chains(self, owner: List[str]):
+        """Flat arrays describing the alignment chain S d S d ... S of every utterance
+        (hidden_markov_model.py:638-664, 794-797), built without per-utterance Python work:
+        chain offsets, model state of every chain position, its 3-band transitions (keys that
+        cross a word boundary are missing in the reference's stacked store and read 0.0),
+        start flags and the ordinal of the word each position belongs to."""
+        base, n_total = self._layout()
+        labels = self._models_loaded
+        model_band = np.concatenate([self._trainable_models[lab]._log_transition_probs.band() for lab in labels], axis=1)
+        cache = self.__dict__.get("_chain_cache")
+        if cache is not None and cache["owner"] is owner:      # the structure only depends on the label strings
+            off, ids, start, ordinal, cross1, cross2 = cache["arrays"]
+            band = model_band[:, ids]
+            band[1, cross1] = 0.0
+            band[2, cross2] = 0.0
+            return off, ids, band.astype(np.float32), start, ordinal, n_total
+        sizes = np.array([self._trainable_models[lab].num_of_states for lab in labels], dtype=np.int64)
+        bases = np.array([base[lab] for lab in labels], dtype=np.int64)
+        lut = np.full(256, -1, dtype=np.int64)
+        for i, lab in enumerate(labels):
+            lut[ord(lab)] = i
+        text = "".join(self.insert_silence(d) for d in owner)
+        word = lut[np.frombuffer(text.encode("ascii"), dtype=np.uint8)]
+        if (word < 0).any():
+            raise KeyError("label string contains a word without a model")
+        words_per_utt = np.array([2 * len(d) + 1 for d in owner], dtype=np.int64)
+        utt_of_word = np.repeat(np.arange(len(owner)), words_per_utt)
+        first_word = np.concatenate([[0], np.cumsum(words_per_utt)[:-1]])
+        ordinal_of_word = np.arange(word.shape[0]) - first_word[utt_of_word]
+        wsize = sizes[word]
+        wstart = np.concatenate([[0], np.cumsum(wsize)[:-1]])
+        total = int(wsize.sum())
+        pos_in_word = np.arange(total) - np.repeat(wstart, wsize)
+        ids = np.repeat(bases[word], wsize) + pos_in_word
+        ordinal = np.repeat(ordinal_of_word, wsize)
+        band = model_band[:, ids].copy()
+        later = ordinal > 0                       # not the first word of its utterance
+        cross1 = np.nonzero(later & (pos_in_word == 0))[0]
+        cross2 = np.nonzero(later & (pos_in_word <= 1))[0]
+        band[1, cross1] = 0.0
+        band[2, cross2] = 0.0
+        chain_len = np.bincount(utt_of_word, weights=wsize, minlength=len(owner)).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(chain_len)]).astype(np.int64)
+        start = np.zeros(total, dtype=np.uint8)
+        start[off[:-1]] = 1
+        ids = ids.astype(np.int32)
+        ordinal = ordinal.astype(np.int64)
+        self.__dict__["_chain_cache"] = {"owner": owner, "arrays": (off, ids, start, ordinal, cross1, cross2)}
+        return off, ids, band.astype(np.float32), start, ordinal, n_total
+
     def _align(self, fb, owner: List[str]):
         """Forced alignment of every utterance against S d S d ... S (hidden_markov_model.py:772-782)
         in one device call.  Returns per-frame arrays: path (chain position), global model state,
         ordinal of the word within its chain."""
         eng = _native.get_engine()
-        base, n_total = self._layout()
         models = [self._trainable_models[lab] for lab in self._models_loaded]
         eng.set_model(_native.new_token(), *stack_gaussians([g for m in models for g in m._multivariate_normals]))
-        per_string = {}
-        for digits in dict.fromkeys(owner):
-            chain = self.insert_silence(digits)
-            ltp, _, mb = _stack([_Labelled(c, self._trainable_models[c]) for c in chain])
-            ids = np.concatenate([base[c] + np.arange(self._trainable_models[c].num_of_states) for c in chain])
-            ordinal = np.concatenate([np.full(self._trainable_models[c].num_of_states, k) for k, c in enumerate(chain)])
-            start = np.zeros(ids.shape[0], dtype=np.uint8)
-            start[0] = 1
-            per_string[digits] = (ids.astype(np.int32), ltp.band(), start, ordinal.astype(np.int32))
-        lens = np.array([per_string[d][0].shape[0] for d in owner], dtype=np.int64)
-        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        ids = np.concatenate([per_string[d][0] for d in owner])
-        band = np.concatenate([per_string[d][1] for d in owner], axis=1)
-        start = np.concatenate([per_string[d][2] for d in owner])
-        ordinal = np.concatenate([per_string[d][3] for d in owner])
+        off, ids, band, start, ordinal, n_total = self._chains(owner)
         _, paths, _ = eng.decode_chain(fb, off, ids, band, start)
         path = paths.cpu().numpy().astype(np.int64)
         utt_of_frame = np.repeat(np.arange(fb.n), fb.lengths)
         pos = off[utt_of_frame] + path
-        return path, ids[pos].astype(np.int64), ordinal[pos].astype(np.int64), utt_of_frame, n_total
+        return path, ids[pos].astype(np.int64), ordinal[pos], utt_of_frame, n_total
 
     def _iteration(self, labeled_mfccs: Dict[str, List[np.ndarray]]) -> None:
         """Alignment + re-mux + statistics + per-word M-step (hidden_markov_model.py:733-770) without
