@@ -1,0 +1,194 @@
+"""Drop-in surface on the device: persistence round trips, pickling, error behaviour of the C ABI,
+size limits, and training on synthetic speech against the oracle's trainers."""
+import ctypes
+import pickle
+
+import numpy as np
+import pytest
+
+from helpers import rel_err, trainable, trans_close
+from oracle import hmm_oracle as O
+from oracle import mfcc_oracle as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def words():
+    from loe_speech_recognition_amd import synthetic
+
+    return synthetic.load_word_models()
+
+
+def test_save_and_from_folder_round_trip(tmp_path, words):
+    from loe_speech_recognition_amd import (MFCC, HiddenMarkovModel, HiddenMarkovModelInference,
+                                            HiddenMarkovModelTrainContinuous, ModelCollection, synthetic)
+
+    for m in words.values():
+        m.save(str(tmp_path))
+    sigs, truth = synthetic.batch(3, 6, 3, start=7000)
+    feats = MFCC.batch(sigs, 16000)
+    direct = HiddenMarkovModelInference.from_models([words[lab] for lab in synthetic.LOOP_ORDER])
+    loaded = HiddenMarkovModelInference.from_folder(str(tmp_path), synthetic.WORDS + ["S"])
+    assert loaded._model_boundaries._labels == synthetic.LOOP_ORDER           # sorted(os.listdir) order
+    for inf in (direct, loaded):
+        inf._log_transition_probability_between_words = -100
+    assert loaded.predict_batch(feats) == direct.predict_batch(feats) == truth
+    one = HiddenMarkovModel.from_folder(str(tmp_path / "4"))
+    s0, p0 = words["4"].predict(feats[0])
+    s1, p1 = one.predict(feats[0])
+    assert s0 == s1 and np.array_equal(p0, p1)
+    mc = ModelCollection.load_from_files(str(tmp_path))
+    assert [str(m) for m in mc._models] == list(synthetic.WORDS)
+    iso, t_iso = synthetic.batch(2, 11, 1, start=300)
+    # isolated classification of one-digit clips cut to the word (silence belongs to no digit model)
+    tc = HiddenMarkovModelTrainContinuous.from_folder(str(tmp_path), synthetic.WORDS + ["S"])
+    assert sorted(tc._trainable_models) == sorted(synthetic.WORDS + ["S"])
+    assert np.all(tc._trainable_models["S"]._means == 0) and tc._trainable_models["S"].num_of_states == 3
+    with pytest.raises(FileNotFoundError):
+        HiddenMarkovModel.from_folder(str(tmp_path / "nope"))
+
+
+def test_objects_pickle_and_keep_working(words):
+    from loe_speech_recognition_amd import MFCC, HiddenMarkovModelInference, ModelCollection, synthetic
+
+    inf = HiddenMarkovModelInference.from_models([words[lab] for lab in synthetic.LOOP_ORDER])
+    inf._log_transition_probability_between_words = -100
+    sigs, truth = synthetic.batch(3, 4, 2, start=8000)
+    feats = MFCC.batch(sigs, 16000)
+    before = inf.predict_batch(feats)
+    clone = pickle.loads(pickle.dumps(inf))
+    assert clone.predict_batch(feats) == before == truth
+    mc = ModelCollection()
+    mc._models = [words[lab] for lab in synthetic.WORDS]
+    mc.predict(feats[0])
+    assert pickle.loads(pickle.dumps(mc)).scores_batch(feats).shape == (4, 11)
+
+
+def test_isolated_classifier_on_word_clips(words):
+    from loe_speech_recognition_amd import MFCC, ModelCollection, synthetic
+
+    mc = ModelCollection()
+    mc._models = [words[lab] for lab in synthetic.WORDS]
+    rng = np.random.default_rng(21)
+    labels = [synthetic.WORDS[i % 11] for i in range(44)]
+    feats = MFCC.batch([synthetic.word_clip(lab, rng) for lab in labels], 16000)
+    got = mc.predict_batch(feats)
+    arrays = synthetic.load_word_arrays()
+    ref_models = [O.WordModelRef(lab, *arrays[lab]) for lab in synthetic.WORDS]
+    assert got == [O.classify_isolated(ref_models, x) for x in feats]
+    assert np.mean([a == b for a, b in zip(got, labels)]) > 0.9
+
+
+def test_c_abi_rejects_bad_arguments():
+    from loe_speech_recognition_amd import _native
+
+    eng = _native.get_engine()
+    lib = eng.lib
+    null = ctypes.c_void_p(0)
+    assert lib.lsr_mfcc_batch(eng.ctx, null, null, null, 1, 10, null) == -1
+    assert b"null" in lib.lsr_last_error(eng.ctx)
+    d = (ctypes.c_double * 4)()
+    assert lib.lsr_model_upload(eng.ctx, 0, d, d, d) == -1
+    assert lib.lsr_model_upload(eng.ctx, 5000, d, d, d) == -3
+    band = np.zeros((3, 70), np.float32)
+    lo = np.array([0], np.int32)
+    up = np.array([69], np.int32)
+    rc = lib.lsr_loop_graph_upload(eng.ctx, 70, 1, band.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                   lo.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                   up.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), -1)
+    assert rc == -3 and b"64" in lib.lsr_last_error(eng.ctx)
+    assert lib.lsr_loop_set_between(eng.ctx, ctypes.c_double(float("nan")), 0) == -1
+    assert lib.lsr_profile_get(eng.ctx, 99, None, None) == -1
+    fresh = ctypes.c_void_p()
+    assert lib.lsr_ctx_create(0, ctypes.byref(fresh)) == 0
+    x = eng.empty((64, 39), eng.torch.float32)
+    assert lib.lsr_emission_batch(fresh, ctypes.c_void_p(x.data_ptr()), 64, ctypes.c_void_p(x.data_ptr())) == -4   # no model yet
+    assert lib.lsr_ctx_destroy(fresh) == 0
+    assert lib.lsr_ctx_create(99, ctypes.byref(fresh)) != 0
+
+
+def test_sixty_four_state_chain_and_limit():
+    """Largest supported alignment chain (64 positions) against the oracle; 65 is refused."""
+    from loe_speech_recognition_amd import HiddenMarkovModelMultiWord
+
+    rng = np.random.default_rng(33)
+    parts = {}
+    for lab, n in (("a", 5), ("b", 5), ("c", 4), ("S", 3)):
+        means = (rng.standard_normal((n, 39)) * 2).astype(np.float32)
+        cov = np.stack([(lambda a: (a @ a.T / 39 + 1e-2 * np.eye(39)))(rng.standard_normal((39, 39))) for _ in range(n)]).astype(np.float32)
+        trans = np.zeros((n, n), np.float32)
+        for s in range(n):
+            w = rng.uniform(0.2, 1, size=min(3, n - s))
+            trans[s, s:s + len(w)] = w / w.sum()
+        parts[lab] = (means, cov, trans)
+    prod = {lab: trainable(lab, *p) for lab, p in parts.items()}
+    chain = "SaSbSaSbSaScScScS"                       # 9*3 + 5*5 + 3*4 = 64 states
+    n_states = sum(parts[c][0].shape[0] for c in chain)
+    assert n_states == 64
+    hmm = HiddenMarkovModelMultiWord.from_labels(chain, prod)
+    seq = np.concatenate([parts[c][0] for c in chain])
+    idx = np.minimum(np.arange(200) * 64 // 200, 63)
+    x = (seq[idx] + 0.5 * rng.standard_normal((200, 39))).astype(np.float32)
+    score, path = hmm.predict(x)
+    ltp, gauss, _ = O.stack_models([O.WordModelRef(c, *parts[c]) for c in chain])
+    mu, U, ld = O.export_gaussians(gauss)
+    s_ref, p_ref, _ = O.viterbi_chain_fast(O.emission_fast(x, mu, U, ld), O.band_from_ltp(ltp, 64))
+    assert score == s_ref and np.array_equal(path, p_ref)
+    too_long = HiddenMarkovModelMultiWord.from_labels(chain + "aS", prod)
+    with pytest.raises(ValueError):
+        too_long.predict(x)
+
+
+def test_isolated_training_on_synthetic_words_matches_oracle():
+    from loe_speech_recognition_amd import MFCC, HiddenMarkovModelTrainable, synthetic
+
+    rng = np.random.default_rng(5)
+    utts = MFCC.batch([synthetic.word_clip("7", rng) for _ in range(20)], 16000)
+    try:
+        ref = O.WordModelRef.from_data("7", utts, n_states=5, max_iterations=8)
+    except O.EmptyStateError:
+        with pytest.raises(HiddenMarkovModelTrainable.HMMTrainMeanFail):
+            HiddenMarkovModelTrainable.from_data("7", utts, num_of_states=5, max_iterations=8, isTqdm=False)
+        return
+    got = HiddenMarkovModelTrainable.from_data("7", utts, num_of_states=5, max_iterations=8, isTqdm=False)
+    assert rel_err(got._means, ref.means) <= 1e-4
+    assert rel_err(got._covariances, ref.cov) <= 1e-4
+    assert trans_close(got._transition_probs.to_array(), ref.trans)
+
+
+def test_continuous_iteration_on_synthetic_speech_matches_oracle(words):
+    """Config 4 at reduced size: 72 clips of 1-7 digits, one forced-alignment + re-estimation pass."""
+    from loe_speech_recognition_amd import MFCC, HiddenMarkovModelTrainContinuous, synthetic
+
+    sigs, truth = synthetic.batch(4, 72, [1, 2, 3, 4, 5, 7])
+    feats = MFCC.batch(sigs, 16000)
+    labeled = {}
+    for x, d in zip(feats, truth):
+        labeled.setdefault(d, []).append(x)
+    arrays = synthetic.load_word_arrays()
+    order = synthetic.WORDS + ["S"]
+    ref = {lab: O.WordModelRef(lab, *arrays[lab]) for lab in order}
+    for m in ref.values():                       # the trainer restarts means at zero (hidden_markov_model.py:696-705)
+        m.means = np.zeros_like(m.means)
+    try:
+        O.continuous_iteration(ref, labeled)
+        failed = False
+    except O.EmptyStateError:
+        failed = True
+    tc = HiddenMarkovModelTrainContinuous(isTqdm=False)
+    fresh = synthetic.load_word_models()
+    for lab in order:
+        tc.add_model(fresh[lab])
+    if failed:
+        with pytest.raises(Exception):
+            tc._iteration(labeled)
+        return
+    tc._iteration(labeled)
+    for lab in order:
+        t = tc._trainable_models[lab]
+        assert rel_err(t._means, ref[lab].means) <= 1e-4, lab
+        assert rel_err(t._covariances, ref[lab].cov) <= 1e-4, lab
+        assert trans_close(t._transition_probs.to_array(), ref[lab].trans), lab
+    # train() drives the same iteration and stops on convergence or after max_iterations
+    tc.train(labeled, max_iterations=2)
