@@ -258,7 +258,7 @@ extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     lsr_frontend_free(ctx);
     free_ptr(ctx->d_wfrag);
-    free_ptr(ctx->d_mean);
+    free_ptr(ctx->d_cfrag);
     free_ptr(ctx->d_lognorm);
     free_ptr(ctx->d_band);
     free_ptr(ctx->d_flags);
@@ -299,10 +299,21 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     if (n_states > 4096) return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_model_upload: %d states > 4096", n_states);
     const int D = LSR_DIM;
     std::vector<double> frag((size_t)n_states * LSR_KSTEPS * LSR_JTILES * 64, 0.0);
-    std::vector<double> mu((size_t)n_states * LSR_KPAD, 0.0);
+    std::vector<double> cinit((size_t)n_states * LSR_JTILES * 64 * 4, 0.0);
     bool triangular = true;          // zero above the diagonal: feature k only feeds components j <= k
     for (int s = 0; s < n_states; ++s) {
-        for (int k = 0; k < D; ++k) mu[(size_t)s * LSR_KPAD + k] = mean[(size_t)s * D + k];
+        // c[j] = sum_k mean[k] U[k][j] (extended precision, rounded once); lane l, register r of the
+        // C tile of row tile a holds row 16a + (l >> 4) + 4r
+        for (int a = 0; a < LSR_JTILES; ++a)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * a + (lane >> 4) + 4 * r;
+                    if (j >= D) continue;
+                    long double acc = 0.0L;
+                    for (int k = 0; k < D; ++k)
+                        acc += (long double)mean[(size_t)s * D + k] * (long double)whiten[((size_t)s * D + k) * D + j];
+                    cinit[(((size_t)s * LSR_JTILES + a) * 64 + lane) * 4 + r] = -(double)acc;
+                }
         for (int k = 0; k < D; ++k)
             for (int j = k + 1; j < D; ++j)
                 if (whiten[((size_t)s * D + k) * D + j] != 0.0) triangular = false;
@@ -318,7 +329,7 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     ctx->whiten_triangular = triangular;
     int rc;
     if ((rc = upload(ctx, &ctx->d_wfrag, frag.data(), frag.size(), "whitening fragments"))) return rc;
-    if ((rc = upload(ctx, &ctx->d_mean, mu.data(), mu.size(), "means"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_cfrag, cinit.data(), cinit.size(), "mean offsets"))) return rc;
     if ((rc = upload(ctx, &ctx->d_lognorm, log_norm, (size_t)n_states, "log normalisers"))) return rc;
     ctx->n_states = n_states;
     return LSR_OK;

@@ -2,12 +2,16 @@
 //
 //   ll[f][s] = float32( -0.5 * (log_norm[s] + sum_j ( sum_k (x[f][k] - mean[s][k]) * U[s][k][j] )^2 ) )
 //
+// evaluated as sum_j ( sum_k x[f][k] U[s][k][j] - c[s][j] )^2 with c = mean U precomputed on the
+// host: the accumulators start at -c, so the matrix unit does all the arithmetic of the
+// whitening (float64 vector adds would compete with the float64 MFMAs for the same pipe).
+//
 // One wavefront owns 64 consecutive frames (4 column tiles of 16 frames) and walks over all
 // states.  A state is three row tiles of 16 whitened components; a row tile is k-steps
 // ks_begin[a]..9 of v_mfma_f64_16x16x4_f64 for each of the 4 frame tiles, with
 // A = U_s^T fragments (coalesced 512-byte loads from the pre-swizzled table built by
-// lsr_model_upload, fetched one row tile ahead of their use) and B = (x - mean_s) formed in
-// registers.  The accumulators of a row tile are squared and summed in-lane; after the third
+// lsr_model_upload, fetched one row tile ahead of their use) and B = x, held in registers for
+// the whole kernel.  The accumulators of a row tile are squared and summed in-lane; after the third
 // tile the four 16-lane groups (rows of the C tiles) are folded so that lane l holds the score
 // of frame l, which goes to an LDS tile and from there to memory in 256-byte rows.
 //
@@ -22,7 +26,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <int KB1, int KB2>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
-    const double* __restrict__ mean, const double* __restrict__ lognorm, int n_states,
+    const v4d* __restrict__ cfrag, const double* __restrict__ lognorm, int n_states,
     float* __restrict__ ll) {
     // [frame][state ^ frame]: the XOR keeps both the per-frame writes and the per-row reads
     // on distinct LDS banks without padding (4 x 16 KiB = the 64 KiB static limit)
@@ -47,14 +51,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
 
     const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
     const double* wf = wfrag + lane;          // [state][row tile][k-step][lane]
-    const double* mu = mean + grp;            // [state][40]
+    const v4d* cf = cfrag + lane;             // [state][row tile][lane]: -c for the lane's 4 rows of the C tile
 
-    double wc[LSR_KSTEPS], wn[LSR_KSTEPS], m[LSR_KSTEPS];
+    double wc[LSR_KSTEPS], wn[LSR_KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
-        wc[ks] = wf[ks * 64];
-        m[ks] = mu[4 * ks];
-    }
+    for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = wf[ks * 64];
+    v4d cc = cf[0], cn;
 
     for (int s = 0; s < n_states; ++s) {
         double ss[4] = {0.0, 0.0, 0.0, 0.0};
@@ -70,22 +72,19 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
 #pragma unroll
                 for (int ks = 0; ks < LSR_KSTEPS; ++ks)
                     if (ks >= nkb) wn[ks] = src[ks * 64];
+                cn = cf[(more ? nxt : 0) * 64];
             }
             v4d acc[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+            for (int q = 0; q < 4; ++q) acc[q] = cc;
 #pragma unroll
             for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
                 if (ks >= kb) {
                     const double w = wc[ks];
-                    // the differences are re-formed for every row tile (three adds are cheaper than
-                    // 80 live registers); the empty asm keeps the compiler from hoisting them
-                    double mk = m[ks];
-                    asm volatile("" : "+v"(mk));
-                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[0][ks] - mk, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[1][ks] - mk, acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[2][ks] - mk, acc[2], 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[3][ks] - mk, acc[3], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[0][ks], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[1][ks], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[2][ks], acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[3][ks], acc[3], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -94,12 +93,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
                 for (int r = 0; r < 4; ++r) ss[q] = fma(acc[q][r], acc[q][r], ss[q]);
 #pragma unroll
             for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = wn[ks];
+            cc = cn;
         }
         const double ln = lognorm[s];
-        if (s + 1 < n_states) {
-#pragma unroll
-            for (int ks = 0; ks < LSR_KSTEPS; ++ks) m[ks] = mu[(size_t)(s + 1) * LSR_KPAD + 4 * ks];
-        }
         // fold the four lane groups (rows of the C tiles) so that group g keeps frame tile g
         const double keep_a = hi32 ? ss[2] : ss[0], send_a = hi32 ? ss[0] : ss[2];
         const double keep_b = hi32 ? ss[3] : ss[1], send_b = hi32 ? ss[1] : ss[3];
@@ -125,10 +121,10 @@ int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames
     lsr_prof_begin(ctx, LSR_K_EMISSION);
     if (ctx->whiten_triangular)
         hipLaunchKernelGGL((lsr_emission_kernel<4, 8>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
-                           feats_d, total_frames, ctx->d_wfrag, ctx->d_mean, ctx->d_lognorm, ctx->n_states, ll_d);
+                           feats_d, total_frames, ctx->d_wfrag, (const v4d*)ctx->d_cfrag, ctx->d_lognorm, ctx->n_states, ll_d);
     else
         hipLaunchKernelGGL((lsr_emission_kernel<0, 0>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
-                           feats_d, total_frames, ctx->d_wfrag, ctx->d_mean, ctx->d_lognorm, ctx->n_states, ll_d);
+                           feats_d, total_frames, ctx->d_wfrag, (const v4d*)ctx->d_cfrag, ctx->d_lognorm, ctx->n_states, ll_d);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_emission_kernel");
     return LSR_OK;

@@ -36,7 +36,7 @@ struct lsr_ctx {
     int n_states = 0;
     double* d_wfrag = nullptr;       // [S][3][10][64]  MFMA A-operand fragments of U^T
     bool whiten_triangular = false;  // every whitening matrix is zero above the diagonal
-    double* d_mean = nullptr;        // [S][40]
+    double* d_cfrag = nullptr;       // [S][3][64][4]  -(mean U)[j] laid out as the initial MFMA accumulator
     double* d_lognorm = nullptr;     // [S]
 
     // loop graph (device)
