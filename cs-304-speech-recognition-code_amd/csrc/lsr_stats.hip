@@ -115,3 +115,67 @@ int lsr_launch_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, 
     LSR_LAUNCH_CHECK(ctx, "lsr_stats_reduce_kernel");
     return LSR_OK;
 }
+
+// ---- path -> statistics slots and transition counts (integer work, one thread per frame) -------------
+__global__ void lsr_utt_index_kernel(const int64_t* __restrict__ frame_off, int32_t* __restrict__ frame_utt) {
+    const int b = blockIdx.x;
+    const int64_t lo = frame_off[b], hi = frame_off[b + 1];
+    for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) frame_utt[f] = b;
+}
+
+__global__ __launch_bounds__(256) void lsr_remux_kernel(const int8_t* __restrict__ paths,
+                                                        const int64_t* __restrict__ frame_off,
+                                                        const int64_t* __restrict__ chain_off,
+                                                        const int32_t* __restrict__ chain_state,
+                                                        const int32_t* __restrict__ chain_word,
+                                                        const int32_t* __restrict__ frame_utt, int64_t total_frames,
+                                                        int n_states, int drop_last_run, int32_t* __restrict__ slots,
+                                                        unsigned long long* __restrict__ trans) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= total_frames) return;
+    const int b = frame_utt[f];
+    const int64_t c0 = chain_off[b], n_chain = chain_off[b + 1] - c0;
+    const int64_t last = frame_off[b + 1] - 1;
+    const int p = paths[f];
+    if (p < 0 || p >= n_chain) {        // only a one-frame utterance has no back-pointer (-1)
+        slots[f] = -1;
+        return;
+    }
+    const int pl = paths[last];
+    const int w_last = (pl >= 0 && pl < n_chain) ? chain_word[c0 + pl] : -1;
+    const int g = chain_state[c0 + p], w = chain_word[c0 + p];
+    const bool keep = !drop_last_run || w != w_last;
+    slots[f] = (keep && g >= 0 && g < n_states) ? g : -1;
+    if (keep && f < last) {
+        const int p1 = paths[f + 1];
+        if (p1 >= 0 && p1 < n_chain) {
+            const int g1 = chain_state[c0 + p1], w1 = chain_word[c0 + p1];
+            const bool keep1 = !drop_last_run || w1 != w_last;
+            if (keep1 && w1 == w && g >= 0 && g < n_states && g1 >= 0 && g1 < n_states)
+                atomicAdd(&trans[(size_t)g * n_states + g1], 1ull);
+        }
+    }
+}
+
+extern "C" int lsr_remux_slots(lsr_ctx* ctx, const int8_t* paths_d, const int64_t* frame_off_d,
+                               const int64_t* chain_off_d, const int32_t* chain_state_d, const int32_t* chain_word_d,
+                               int n_utts, int64_t total_frames, int n_states, int drop_last_run, int32_t* slots_d,
+                               int64_t* trans_d) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!paths_d || !frame_off_d || !chain_off_d || !chain_state_d || !chain_word_d || !slots_d || !trans_d)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_remux_slots: null pointer");
+    if (n_utts < 1 || total_frames < n_utts || n_states < 1 || n_states > 4096)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_remux_slots: bad sizes");
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc = lsr_reserve(ctx, &ctx->ws_frame_utt, (size_t)total_frames * sizeof(int32_t), "frame index");
+    if (rc) return rc;
+    int32_t* frame_utt = (int32_t*)ctx->ws_frame_utt.ptr;
+    LSR_HIP_CHECK(ctx, hipMemsetAsync(trans_d, 0, (size_t)n_states * n_states * sizeof(int64_t), ctx->stream));
+    hipLaunchKernelGGL(lsr_utt_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, frame_off_d, frame_utt);
+    LSR_LAUNCH_CHECK(ctx, "lsr_utt_index_kernel");
+    hipLaunchKernelGGL(lsr_remux_kernel, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, ctx->stream, paths_d,
+                       frame_off_d, chain_off_d, chain_state_d, chain_word_d, frame_utt, total_frames, n_states,
+                       drop_last_run, slots_d, (unsigned long long*)trans_d);
+    LSR_LAUNCH_CHECK(ctx, "lsr_remux_kernel");
+    return LSR_OK;
+}

@@ -59,6 +59,7 @@ def _declare(lib) -> None:
         "lsr_recognize_batch": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_decode_chain_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, c_int64, P, P, P, P, P, P]),
         "lsr_accumulate_stats": (c_int, [P, P, P, c_int64, c_int, P, P, P]),
+        "lsr_remux_slots": (c_int, [P, P, P, P, P, P, c_int, c_int64, c_int, c_int, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not export a declared symbol
@@ -71,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "lsr_profile_enable", "lsr_profile_reset", "lsr_profile_get", "lsr_host_hann_window",
     "lsr_host_mel_filterbank", "lsr_host_dct_matrix", "lsr_model_upload", "lsr_loop_graph_upload",
     "lsr_loop_set_between", "lsr_mfcc_batch", "lsr_emission_batch", "lsr_decode_loop_batch",
-    "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats",
+    "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
 ]
 
 
@@ -321,6 +322,7 @@ class Engine:
         assert chain_start.shape == (total_chain,)
         d_off, d_state = self.to_device(chain_off), self.to_device(chain_state)
         d_band, d_start = self.to_device(chain_band), self.to_device(chain_start)
+        self.last_chain = (d_off, d_state)           # device copies, reused by remux_slots
         scores = self.empty((fb.n,), t.float32)
         paths = self.empty((fb.total_frames,), t.int8) if want_paths else None
         final = self.empty((fb.n, 64), t.float32) if want_final else None
@@ -330,6 +332,18 @@ class Engine:
                                                     self._ptr(scores), self._ptr(paths), self._ptr(final)))
         self.synchronize()     # the chain arrays above must outlive the kernels
         return scores, paths, final
+
+    def remux_slots(self, paths, fb: "FeatureBatch", chain_off, chain_state, chain_word, n_states: int,
+                    drop_last_run: bool):
+        """(slots int32[total_frames], transition counts int64[n_states, n_states]) device tensors.
+        chain_* are device tensors (int64 offsets, int32 state and word ordinal per chain position)."""
+        t = self.torch
+        slots = self.empty((fb.total_frames,), t.int32)
+        trans = self.empty((n_states, n_states), t.int64)
+        self._check(self.lib.lsr_remux_slots(self.ctx, self._ptr(paths), self._ptr(fb.frame_off), self._ptr(chain_off),
+                                             self._ptr(chain_state), self._ptr(chain_word), fb.n, fb.total_frames,
+                                             n_states, 1 if drop_last_run else 0, self._ptr(slots), self._ptr(trans)))
+        return slots, trans
 
     def accumulate_stats(self, fb_feats, slots, total_frames: int, n_slots: int):
         """(count f64[n], sum_x f64[n,39], sum_xx f64[n,39,39]) device tensors."""

@@ -255,13 +255,13 @@ class HiddenMarkovModelTrainable(HiddenMarkovModel):
         n = ids.shape[0]
         off = np.arange(fb.n + 1, dtype=np.int64) * n
         _, paths, _ = eng.decode_chain(fb, off, np.tile(ids, fb.n), np.tile(band, (1, fb.n)), np.tile(start, fb.n))
-        slots = paths.to(eng.torch.int32)            # a left-to-right path is non-decreasing: slot = state
+        # a left-to-right path never decreases, so every frame feeds the state it is aligned to
+        # (signal.py:23-47) and consecutive frames of an utterance count as one transition (signal.py:80-91)
+        d_off, d_ids = eng.last_chain
+        word = eng.torch.zeros(d_ids.shape[0], dtype=eng.torch.int32, device=eng.device)
+        slots, trans = eng.remux_slots(paths, fb, d_off, d_ids, word, n, drop_last_run=False)
         count, sum_x, sum_xx = _stats_to_host(*eng.accumulate_stats(fb.feats, slots, fb.total_frames, n))
-        p = paths.cpu().numpy().astype(np.int64)
-        same_utt = np.ones(p.shape[0] - 1, dtype=bool)
-        same_utt[fb.host_off[1:-1] - 1] = False
-        trans = np.bincount(p[:-1][same_utt] * n + p[1:][same_utt], minlength=n * n).reshape(n, n)
-        self._m_step(count, sum_x, sum_xx, trans)
+        self._m_step(count, sum_x, sum_xx, trans.cpu().numpy())
 
     def _m_step(self, count: np.ndarray, sum_x: np.ndarray, sum_xx: np.ndarray, trans_counts: np.ndarray) -> None:
         """hidden_markov_model.py:320-350 from reduced statistics: mean = sum_x / n,
@@ -616,34 +616,31 @@ class HiddenMarkovModelTrainContinuous:
 
     def _align(self, fb, owner: List[str]):
         """Forced alignment of every utterance against S d S d ... S (hidden_markov_model.py:772-782)
-        in one device call.  Returns per-frame arrays: path (chain position), global model state,
-        ordinal of the word within its chain."""
+        in one device call.  Returns the device paths (chain positions) and the chain description."""
         eng = _native.get_engine()
         models = [self._trainable_models[lab] for lab in self._models_loaded]
         eng.set_model(_native.new_token(), *stack_gaussians([g for m in models for g in m._multivariate_normals]))
         off, ids, band, start, ordinal, n_total = self._chains(owner)
         _, paths, _ = eng.decode_chain(fb, off, ids, band, start)
-        path = paths.cpu().numpy().astype(np.int64)
-        utt_of_frame = np.repeat(np.arange(fb.n), fb.lengths)
-        pos = off[utt_of_frame] + path
-        return path, ids[pos].astype(np.int64), ordinal[pos], utt_of_frame, n_total
+        return paths, off, ids, ordinal, n_total
 
     def _iteration(self, labeled_mfccs: Dict[str, List[np.ndarray]]) -> None:
         """Alignment + re-mux + statistics + per-word M-step (hidden_markov_model.py:733-770) without
         materialising per-word Signal objects: a frame contributes to the model state it is aligned
         to unless it belongs to the last word run of its utterance (the reference never flushes that
-        run, hidden_markov_model.py:614-634)."""
+        run, hidden_markov_model.py:614-634).  Paths, slots and statistics stay on the device; one
+        packed float64 vector comes back (after the all-reduce when several ranks train together)."""
         eng = _native.get_engine()
+        t = eng.torch
         fb, owner = self._prepare(labeled_mfccs)
-        _, gstate, ordinal, utt, n_total = self._align(fb, owner)
-        last_ord = ordinal[fb.host_off[1:] - 1]
-        keep = ordinal != last_ord[utt]
-        slots = np.where(keep, gstate, -1).astype(np.int32)
-        count, sum_x, sum_xx = eng.accumulate_stats(fb.feats, eng.to_device(slots), fb.total_frames, n_total)
-        pair = keep[:-1] & keep[1:] & (utt[:-1] == utt[1:]) & (ordinal[:-1] == ordinal[1:])
-        trans = np.bincount(gstate[:-1][pair] * n_total + gstate[1:][pair], minlength=n_total * n_total)
-        trans = trans.reshape(n_total, n_total).astype(np.float64)
-        stats = eng.torch.cat([count, sum_x.reshape(-1), sum_xx.reshape(-1), eng.to_device(trans.reshape(-1))])
+        paths, off, ids, ordinal, n_total = self._align(fb, owner)
+        d_off, d_ids = eng.last_chain
+        cache = self.__dict__["_chain_cache"]
+        if "d_ordinal" not in cache:
+            cache["d_ordinal"] = eng.to_device(ordinal.astype(np.int32))
+        slots, trans = eng.remux_slots(paths, fb, d_off, d_ids, cache["d_ordinal"], n_total, drop_last_run=True)
+        count, sum_x, sum_xx = eng.accumulate_stats(fb.feats, slots, fb.total_frames, n_total)
+        stats = t.cat([count, sum_x.reshape(-1), sum_xx.reshape(-1), trans.reshape(-1).to(t.float64)])
         stats = all_reduce_stats(stats)
         stats = stats.cpu().numpy()
         d = _native.DIM

@@ -157,6 +157,21 @@ int lsr_accumulate_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot
                          int64_t total_frames, int n_slots, double* count_d, double* sum_x_d,
                          double* sum_xx_d);
 
+/* Replaces the segmentation bookkeeping of HiddenMarkovModelMultiWord._remux_path_and_signal
+ * (hidden_markov_model.py:602-636), Signal.order_by_state (signal.py:23-47) and the transition
+ * counting of SortedSignals.transition_probabilities (signal.py:80-91) for a batch of aligned
+ * utterances: paths_d int8[total_frames] holds chain positions (output of
+ * lsr_decode_chain_batch), chain_state_d / chain_word_d int32[total_chain] give the model state
+ * and the ordinal of the word of every chain position.  slots_d int32[total_frames] receives the
+ * model state each frame contributes to, or -1 when drop_last_run != 0 and the frame belongs to
+ * the last word run of its utterance (the reference only flushes a run when the label changes, so
+ * the final run is never used).  trans_d int64[n_states][n_states] is OVERWRITTEN with the number
+ * of consecutive kept frame pairs (same utterance, same word) per (from, to) model state. */
+int lsr_remux_slots(lsr_ctx* ctx, const int8_t* paths_d, const int64_t* frame_off_d,
+                    const int64_t* chain_off_d, const int32_t* chain_state_d,
+                    const int32_t* chain_word_d, int n_utts, int64_t total_frames, int n_states,
+                    int drop_last_run, int32_t* slots_d, int64_t* trans_d);
+
 #ifdef __cplusplus
 }
 #endif
