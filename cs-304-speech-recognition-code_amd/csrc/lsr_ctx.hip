@@ -393,14 +393,24 @@ static int check_batch(lsr_ctx* ctx, const char* fn, int n_utts, int64_t total_f
     return LSR_OK;
 }
 
-extern "C" int lsr_mfcc_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
-                              const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d) {
+static int mfcc_any(lsr_ctx* ctx, const void* audio_d, int is_i16, const int64_t* sample_off_d,
+                    const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d) {
     if (!ctx) return LSR_ERR_ARG;
     if (!audio_d || !sample_off_d || !frame_off_d || !feats_d) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_mfcc_batch: null pointer");
     int rc = check_batch(ctx, "lsr_mfcc_batch", n_utts, total_frames);
     if (rc) return rc;
     LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    return lsr_launch_mfcc(ctx, audio_d, sample_off_d, frame_off_d, n_utts, total_frames, feats_d);
+    return lsr_launch_mfcc(ctx, audio_d, is_i16, sample_off_d, frame_off_d, n_utts, total_frames, feats_d);
+}
+
+extern "C" int lsr_mfcc_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+                              const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d) {
+    return mfcc_any(ctx, audio_d, 0, sample_off_d, frame_off_d, n_utts, total_frames, feats_d);
+}
+
+extern "C" int lsr_mfcc_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, const int64_t* sample_off_d,
+                                  const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d) {
+    return mfcc_any(ctx, audio_d, 1, sample_off_d, frame_off_d, n_utts, total_frames, feats_d);
 }
 
 extern "C" int lsr_emission_batch(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d) {
@@ -439,19 +449,34 @@ extern "C" int lsr_decode_loop_batch(lsr_ctx* ctx, const float* feats_d, const i
                                    scores_d, paths_d, labels_d, n_labels_d, label_cap);
 }
 
-extern "C" int lsr_recognize_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
-                                   const int64_t* frame_off_d, int n_utts, int64_t total_frames, int max_frames,
-                                   float* scores_d, int8_t* paths_d, uint8_t* labels_d, int32_t* n_labels_d,
-                                   int label_cap) {
+static int recognize_any(lsr_ctx* ctx, const void* audio_d, int is_i16, const int64_t* sample_off_d,
+                         const int64_t* frame_off_d, int n_utts, int64_t total_frames, int max_frames,
+                         float* scores_d, int8_t* paths_d, uint8_t* labels_d, int32_t* n_labels_d, int label_cap) {
     if (!ctx) return LSR_ERR_ARG;
     int rc = check_batch(ctx, "lsr_recognize_batch", n_utts, total_frames);
     if (rc) return rc;
     LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if ((rc = lsr_reserve(ctx, &ctx->ws_feats, (size_t)total_frames * LSR_DIM * sizeof(float), "features"))) return rc;
-    if ((rc = lsr_mfcc_batch(ctx, audio_d, sample_off_d, frame_off_d, n_utts, total_frames, (float*)ctx->ws_feats.ptr)))
+    if ((rc = mfcc_any(ctx, audio_d, is_i16, sample_off_d, frame_off_d, n_utts, total_frames, (float*)ctx->ws_feats.ptr)))
         return rc;
     return lsr_decode_loop_batch(ctx, (const float*)ctx->ws_feats.ptr, frame_off_d, n_utts, total_frames, max_frames,
                                  scores_d, paths_d, labels_d, n_labels_d, label_cap);
+}
+
+extern "C" int lsr_recognize_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+                                   const int64_t* frame_off_d, int n_utts, int64_t total_frames, int max_frames,
+                                   float* scores_d, int8_t* paths_d, uint8_t* labels_d, int32_t* n_labels_d,
+                                   int label_cap) {
+    return recognize_any(ctx, audio_d, 0, sample_off_d, frame_off_d, n_utts, total_frames, max_frames, scores_d, paths_d,
+                         labels_d, n_labels_d, label_cap);
+}
+
+extern "C" int lsr_recognize_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, const int64_t* sample_off_d,
+                                       const int64_t* frame_off_d, int n_utts, int64_t total_frames, int max_frames,
+                                       float* scores_d, int8_t* paths_d, uint8_t* labels_d, int32_t* n_labels_d,
+                                       int label_cap) {
+    return recognize_any(ctx, audio_d, 1, sample_off_d, frame_off_d, n_utts, total_frames, max_frames, scores_d, paths_d,
+                         labels_d, n_labels_d, label_cap);
 }
 
 extern "C" int lsr_decode_chain_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d, int n_utts,

@@ -85,7 +85,7 @@ void lsr_frontend_free(lsr_ctx* ctx);
     } while (0)
 
 // launchers implemented in the kernel translation units
-int lsr_launch_mfcc(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+int lsr_launch_mfcc(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const int64_t* sample_off_d,
                     const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d);
 int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d);
 int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,

@@ -67,7 +67,8 @@ __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, in
 #define MP_SLOT_BINS 6       // bins per mel slot (61 slots cover the 260 non-zero weights)
 
 // samples 2m, 2m+1 (m = 16 n1 + n2, n1 = 0..9) of frame `g` for one lane; zero outside the clip
-__device__ __forceinline__ void mp_load_samples(const float* __restrict__ audio, const int64_t* __restrict__ sample_off,
+template <typename SAMPLE>
+__device__ __forceinline__ void mp_load_samples(const SAMPLE* __restrict__ audio, const int64_t* __restrict__ sample_off,
                                                 const int64_t* __restrict__ frame_off,
                                                 const int32_t* __restrict__ frame_utt, int64_t total_frames, int64_t g,
                                                 int n2, float (&xs)[20]) {
@@ -76,19 +77,19 @@ __device__ __forceinline__ void mp_load_samples(const float* __restrict__ audio,
         const int64_t s0 = sample_off[b];
         const int64_t ns = sample_off[b + 1] - s0;
         const int64_t first = (int64_t)LSR_HOP * (g - frame_off[b]) - LSR_N_FFT / 2;   // centre padding
-        const float* sig = audio + s0 + first + 2 * n2;
+        const SAMPLE* sig = audio + s0 + first + 2 * n2;
         if (first >= 0 && first + LSR_N_FFT <= ns) {
 #pragma unroll
             for (int n1 = 0; n1 < 10; ++n1) {
-                xs[2 * n1] = sig[32 * n1];
-                xs[2 * n1 + 1] = sig[32 * n1 + 1];
+                xs[2 * n1] = (float)sig[32 * n1];
+                xs[2 * n1 + 1] = (float)sig[32 * n1 + 1];
             }
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < 10; ++n1) {
                 const int64_t i0 = first + 2 * n2 + 32 * n1, i1 = i0 + 1;
-                xs[2 * n1] = (i0 >= 0 && i0 < ns) ? sig[32 * n1] : 0.f;
-                xs[2 * n1 + 1] = (i1 >= 0 && i1 < ns) ? sig[32 * n1 + 1] : 0.f;
+                xs[2 * n1] = (i0 >= 0 && i0 < ns) ? (float)sig[32 * n1] : 0.f;
+                xs[2 * n1 + 1] = (i1 >= 0 && i1 < ns) ? (float)sig[32 * n1 + 1] : 0.f;
             }
         }
     } else {
@@ -118,8 +119,9 @@ __device__ __forceinline__ void mp_untangle(const cplx* __restrict__ z, float* _
     if (k != 80) pw[160 - k] = mp_power(e.re - t.re, e.im - t.im);
 }
 
+template <typename SAMPLE>
 __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
-    const float* __restrict__ audio, const int64_t* __restrict__ sample_off, const int64_t* __restrict__ frame_off,
+    const SAMPLE* __restrict__ audio, const int64_t* __restrict__ sample_off, const int64_t* __restrict__ frame_off,
     const int32_t* __restrict__ frame_utt, int64_t total_frames, int64_t n_groups, const double* __restrict__ window,
     const double* __restrict__ tw160, const double* __restrict__ tw320, const float* __restrict__ slot_w,
     const int* __restrict__ slot_info, const int* __restrict__ band_slots, float* __restrict__ mel,
@@ -351,8 +353,8 @@ __global__ __launch_bounds__(256) void lsr_mfcc_finish_kernel(
     for (int i = tid; i < nvalid * LSR_DIM; i += 256) feats[g0 * LSR_DIM + i] = flat[i];
 }
 
-int lsr_launch_mfcc(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d, const int64_t* frame_off_d,
-                    int n_utts, int64_t total_frames, float* feats_d) {
+int lsr_launch_mfcc(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const int64_t* sample_off_d,
+                    const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d) {
     int rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_frame_utt, (size_t)total_frames * sizeof(int32_t), "frame index"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_mel, (size_t)total_frames * LSR_N_MELS * sizeof(float), "mel energies"))) return rc;
@@ -372,9 +374,16 @@ int lsr_launch_mfcc(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_of
     const int64_t n_groups = (total_frames + MP_FRAMES - 1) / MP_FRAMES;
     const unsigned blocks_mp = (unsigned)(n_groups < 256 * 8 ? n_groups : 256 * 8);
     lsr_prof_begin(ctx, LSR_K_MEL_POWER);
-    hipLaunchKernelGGL(lsr_mel_power_kernel, dim3(blocks_mp), dim3(64), 0, ctx->stream, audio_d, sample_off_d,
-                       frame_off_d, frame_utt, total_frames, n_groups, ctx->d_window, ctx->d_tw160, ctx->d_tw320,
-                       ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots, mel, uttmax);
+    if (audio_is_i16)
+        hipLaunchKernelGGL(lsr_mel_power_kernel<int16_t>, dim3(blocks_mp), dim3(64), 0, ctx->stream,
+                           (const int16_t*)audio_d, sample_off_d, frame_off_d, frame_utt, total_frames, n_groups,
+                           ctx->d_window, ctx->d_tw160, ctx->d_tw320, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots,
+                           mel, uttmax);
+    else
+        hipLaunchKernelGGL(lsr_mel_power_kernel<float>, dim3(blocks_mp), dim3(64), 0, ctx->stream,
+                           (const float*)audio_d, sample_off_d, frame_off_d, frame_utt, total_frames, n_groups,
+                           ctx->d_window, ctx->d_tw160, ctx->d_tw320, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots,
+                           mel, uttmax);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_mel_power_kernel");
 

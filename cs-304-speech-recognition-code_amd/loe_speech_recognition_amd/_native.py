@@ -54,6 +54,8 @@ def _declare(lib) -> None:
         "lsr_loop_graph_upload": (c_int, [P, c_int, c_int, POINTER(c_float), POINTER(c_int32), POINTER(c_int32), c_int]),
         "lsr_loop_set_between": (c_int, [P, c_double, c_int]),
         "lsr_mfcc_batch": (c_int, [P, P, P, P, c_int, c_int64, P]),
+        "lsr_mfcc_batch_i16": (c_int, [P, P, P, P, c_int, c_int64, P]),
+        "lsr_recognize_batch_i16": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
         "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_recognize_batch": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
@@ -73,6 +75,7 @@ EXPORTED_SYMBOLS = [
     "lsr_host_mel_filterbank", "lsr_host_dct_matrix", "lsr_model_upload", "lsr_loop_graph_upload",
     "lsr_loop_set_between", "lsr_mfcc_batch", "lsr_emission_batch", "lsr_decode_loop_batch",
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
+    "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16",
 ]
 
 
@@ -203,7 +206,9 @@ class Engine:
         frames = 1 + n // HOP
         if frames.min() < MIN_FRAMES:
             raise ValueError(f"a clip yields {int(frames.min())} frames; the width-9 delta filter needs at least {MIN_FRAMES}")
-        flat = np.concatenate([np.asarray(s, dtype=np.float32) for s in signals])
+        # int16 PCM stays int16 (converted on the device); everything else is float32 like the reference's loader
+        dtype = np.int16 if all(s.dtype == np.int16 for s in signals) else np.float32
+        flat = np.concatenate([np.asarray(s, dtype=dtype) for s in signals])
         soff = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
         foff = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
         return AudioBatch(self.to_device(flat), self.to_device(soff), self.to_device(foff), n)
@@ -224,7 +229,8 @@ class Engine:
     def mfcc(self, batch: AudioBatch):
         """float32 device tensor [total_frames, 39] (time-major)."""
         out = self.empty((batch.total_frames, DIM), self.torch.float32)
-        self._check(self.lib.lsr_mfcc_batch(self.ctx, self._ptr(batch.audio), self._ptr(batch.sample_off),
+        fn = self.lib.lsr_mfcc_batch_i16 if batch.audio.dtype == self.torch.int16 else self.lib.lsr_mfcc_batch
+        self._check(fn(self.ctx, self._ptr(batch.audio), self._ptr(batch.sample_off),
                                             self._ptr(batch.frame_off), batch.n, batch.total_frames, self._ptr(out)))
         return FeatureBatch(out, batch.frame_off, batch.lengths)
 
@@ -297,7 +303,8 @@ class Engine:
             out = (self.empty((ab.n,), t.float32), self.empty((ab.total_frames,), t.int8) if want_paths else None,
                    self.empty((ab.n, label_cap), t.uint8), self.empty((ab.n,), t.int32))
         scores, paths, labels, n_labels = out
-        self._check(self.lib.lsr_recognize_batch(self.ctx, self._ptr(ab.audio), self._ptr(ab.sample_off),
+        fn = self.lib.lsr_recognize_batch_i16 if ab.audio.dtype == self.torch.int16 else self.lib.lsr_recognize_batch
+        self._check(fn(self.ctx, self._ptr(ab.audio), self._ptr(ab.sample_off),
                                                  self._ptr(ab.frame_off), ab.n, ab.total_frames, ab.max_frames,
                                                  self._ptr(scores), self._ptr(paths), self._ptr(labels),
                                                  self._ptr(n_labels), label_cap))

@@ -66,6 +66,21 @@ class MFCC:
         return _native.split_ragged(flat, fb.host_off)
 
     @classmethod
+    def batch_int16(cls, signals: List[np.ndarray], sample_rate: int = 16000) -> List[np.ndarray]:
+        """``batch`` for int16 PCM straight from ``scipy.io.wavfile.read``: the float32 conversion the
+        reference's loader does (ti_digits.py:130-134) happens on the device."""
+        if len(signals) == 0:
+            return []
+        for s in signals:
+            if not isinstance(s, np.ndarray) or s.ndim != 1 or s.dtype != np.int16:
+                raise TypeError("batch_int16 expects 1-dimensional int16 arrays")
+        if float(sample_rate) != 16000.0:
+            raise ValueError("the device front-end is built for 16 kHz audio")
+        eng = _native.get_engine()
+        fb = eng.mfcc(eng.audio_batch(signals))
+        return _native.split_ragged(fb.feats.cpu().numpy(), fb.host_off)
+
+    @classmethod
     def batch_device(cls, signals: List[np.ndarray], sample_rate: int = 16000) -> "_native.FeatureBatch":
         """Same as ``batch`` but the features stay on the device for the decoders/trainers."""
         for s in signals:

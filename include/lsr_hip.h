@@ -103,6 +103,11 @@ int lsr_loop_set_between(lsr_ctx* ctx, double between, int between_is_f64);
  * (time-major, the transposed layout MFCC.batch returns). */
 int lsr_mfcc_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
                    const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d);
+/* Same for int16 PCM as read from a wav file: the conversion of DataLoader.lazy_loading
+ * (ti_digits.py:130-134, wavfile.read(...).astype(float32)) happens on the device, which halves
+ * the bytes uploaded and read. */
+int lsr_mfcc_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, const int64_t* sample_off_d,
+                       const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d);
 
 /* ---- emission scores -------------------------------------------------------------------- */
 /* Replaces MultivariateNormal.log_pdf (hidden_markov_model.py:46-48) for every (frame, state):
@@ -128,6 +133,10 @@ int lsr_recognize_batch(lsr_ctx* ctx, const float* audio_d, const int64_t* sampl
                         const int64_t* frame_off_d, int n_utts, int64_t total_frames,
                         int max_frames, float* scores_d, int8_t* paths_d, uint8_t* labels_d,
                         int32_t* n_labels_d, int label_cap);
+int lsr_recognize_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, const int64_t* sample_off_d,
+                            const int64_t* frame_off_d, int n_utts, int64_t total_frames,
+                            int max_frames, float* scores_d, int8_t* paths_d, uint8_t* labels_d,
+                            int32_t* n_labels_d, int label_cap);
 
 /* Replaces HiddenMarkovModel.predict/_viterbi/_viterbi_static (hidden_markov_model.py:75-91,
  * 160-208) for a batch of per-utterance chains: isolated word models, several independent

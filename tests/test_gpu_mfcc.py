@@ -84,3 +84,23 @@ def test_batch_equals_individual_clips():
     whole = MFCC.batch(sigs, 16000)
     for s, f in zip(sigs, whole):
         assert np.array_equal(MFCC.batch([s], 16000)[0], f)
+
+
+def test_int16_pcm_ingestion_matches_float_path():
+    """wav-file PCM (ti_digits.py:130-134 converts int16 -> float32 on the host) converted on the device."""
+    from loe_speech_recognition_amd import MFCC, HiddenMarkovModelInference, synthetic
+
+    sigs, truth = synthetic.batch(3, 8, 3, start=4000)
+    pcm = [np.clip(np.rint(s), -32768, 32767).astype(np.int16) for s in sigs]
+    as_float = [p.astype(np.float32) for p in pcm]
+    a = MFCC.batch_int16(pcm)
+    b = MFCC.batch(as_float, 16000)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    _check(as_float)
+    models = synthetic.load_word_models()
+    inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
+    inf._log_transition_probability_between_words = -100
+    assert inf.recognize_audio(pcm) == inf.recognize_audio(as_float) == truth
+    with pytest.raises(TypeError):
+        MFCC.batch_int16(as_float)
