@@ -260,6 +260,7 @@ extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
     free_ptr(ctx->d_wfrag);
     free_ptr(ctx->d_cfrag);
     free_ptr(ctx->d_lognorm);
+    free_ptr(ctx->d_logw);
     free_ptr(ctx->d_band);
     free_ptr(ctx->d_flags);
     free_ptr(ctx->d_word_of);
@@ -332,6 +333,22 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     if ((rc = upload(ctx, &ctx->d_cfrag, cinit.data(), cinit.size(), "mean offsets"))) return rc;
     if ((rc = upload(ctx, &ctx->d_lognorm, log_norm, (size_t)n_states, "log normalisers"))) return rc;
     ctx->n_states = n_states;
+    ctx->n_mix = 1;
+    return LSR_OK;
+}
+
+extern "C" int lsr_model_set_mixtures(lsr_ctx* ctx, int n_mix, const double* log_weights) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (ctx->n_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_model_set_mixtures: no model uploaded");
+    if (n_mix < 1 || ctx->n_states % n_mix != 0 || (n_mix > 1 && !log_weights))
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_model_set_mixtures: %d Gaussians cannot form states of %d components", ctx->n_states, n_mix);
+    if (n_mix > 1) {
+        for (int i = 0; i < ctx->n_states; ++i)
+            if (log_weights[i] != log_weights[i]) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_model_set_mixtures: NaN weight");
+        int rc = upload(ctx, &ctx->d_logw, log_weights, (size_t)ctx->n_states, "mixture weights");
+        if (rc) return rc;
+    }
+    ctx->n_mix = n_mix;
     return LSR_OK;
 }
 
@@ -417,8 +434,8 @@ extern "C" int lsr_emission_batch(lsr_ctx* ctx, const float* feats_d, int64_t to
     if (!ctx) return LSR_ERR_ARG;
     if (!feats_d || !ll_d) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_emission_batch: null pointer");
     if (ctx->n_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_emission_batch: no model uploaded");
-    if (ctx->n_states > LSR_LL_STRIDE)
-        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_emission_batch: %d states > %d", ctx->n_states, LSR_LL_STRIDE);
+    if (ctx->n_states / ctx->n_mix > LSR_LL_STRIDE)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_emission_batch: %d states > %d", ctx->n_states / ctx->n_mix, LSR_LL_STRIDE);
     int rc = check_batch(ctx, "lsr_emission_batch", 1, total_frames);
     if (rc) return rc;
     LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -436,8 +453,8 @@ extern "C" int lsr_decode_loop_batch(lsr_ctx* ctx, const float* feats_d, const i
     if (!feats_d || !frame_off_d) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_batch: null pointer");
     if (ctx->n_states == 0 || ctx->g_states == 0)
         return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_loop_batch: model and loop graph must be uploaded first");
-    if (ctx->n_states != ctx->g_states)
-        return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_loop_batch: model has %d states, graph %d", ctx->n_states, ctx->g_states);
+    if (ctx->n_states / ctx->n_mix != ctx->g_states)
+        return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_loop_batch: model has %d states, graph %d", ctx->n_states / ctx->n_mix, ctx->g_states);
     if (labels_d && label_cap < 1) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_batch: label_cap < 1");
     int rc = check_batch(ctx, "lsr_decode_loop_batch", n_utts, total_frames);
     if (rc) return rc;
@@ -487,8 +504,8 @@ extern "C" int lsr_decode_chain_batch(lsr_ctx* ctx, const float* feats_d, const 
     if (!feats_d || !frame_off_d || !chain_off_d || !chain_state_d || !chain_band_d || !chain_start_d)
         return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_chain_batch: null pointer");
     if (ctx->n_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_chain_batch: no model uploaded");
-    if (ctx->n_states > LSR_LL_STRIDE)
-        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_decode_chain_batch: %d model states > %d", ctx->n_states, LSR_LL_STRIDE);
+    if (ctx->n_states / ctx->n_mix > LSR_LL_STRIDE)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_decode_chain_batch: %d model states > %d", ctx->n_states / ctx->n_mix, LSR_LL_STRIDE);
     int rc = check_batch(ctx, "lsr_decode_chain_batch", n_utts, total_frames);
     if (rc) return rc;
     if (max_frames < 1 || total_chain < n_utts) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_chain_batch: bad sizes");

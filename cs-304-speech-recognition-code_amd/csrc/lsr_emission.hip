@@ -15,6 +15,10 @@
 // tile the four 16-lane groups (rows of the C tiles) are folded so that lane l holds the score
 // of frame l, which goes to an LDS tile and from there to memory in 256-byte rows.
 //
+// Mixtures: with n_mix > 1 the n_states Gaussians are n_states / n_mix states of n_mix components
+// each; consecutive components are folded with a sequential float64 log-add-exp of
+// log w + log N (the order NumPy's np.logaddexp loop uses) before the float32 rounding.
+//
 // ks_begin lets a lower-triangular whitening matrix (zero above the diagonal) skip the
 // all-zero k-steps of the second and third row tile; a dense matrix uses 0, 0, 0.
 #include "lsr_internal.h"
@@ -26,8 +30,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <int KB1, int KB2>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
-    const v4d* __restrict__ cfrag, const double* __restrict__ lognorm, int n_states,
-    float* __restrict__ ll) {
+    const v4d* __restrict__ cfrag, const double* __restrict__ lognorm, const double* __restrict__ logw,
+    int n_states, int n_mix, float* __restrict__ ll) {
     // [frame][state ^ frame]: the XOR keeps both the per-frame writes and the per-row reads
     // on distinct LDS banks without padding (4 x 16 KiB = the 64 KiB static limit)
     __shared__ float tile[EM_WAVES][64][64];
@@ -58,6 +62,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
     for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = wf[ks * 64];
     v4d cc = cf[0], cn;
 
+    double run = 0.0;          // log-sum of the components of the current state seen so far
+    int mix = 0;
     for (int s = 0; s < n_states; ++s) {
         double ss[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -103,14 +109,32 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
         const double v1 = keep_b + __shfl_xor(send_b, 32);
         const double keep = hi16 ? v1 : v0, send = hi16 ? v0 : v1;
         const double maha = keep + __shfl_xor(send, 16);
-        tile[wave][lane][(s ^ lane) & 63] = (float)(-0.5 * (ln + maha));
+        const double lp = -0.5 * (ln + maha);
+        if (n_mix == 1) {
+            tile[wave][lane][(s ^ lane) & 63] = (float)lp;
+        } else {
+            const double v = logw[s] + lp;
+            if (mix == 0) {
+                run = v;                                   // logaddexp(-inf, v)
+            } else if (run == v) {
+                run = run + 0.693147180559945309417232121458176568;
+            } else {
+                const double d = run - v;                  // NumPy: x + log1p(exp(-d)) for d > 0, else y + log1p(exp(d))
+                run = d > 0 ? run + log1p(exp(-d)) : (d <= 0 ? v + log1p(exp(d)) : d);
+            }
+            if (++mix == n_mix) {
+                const int col = s / n_mix;
+                tile[wave][lane][(col ^ lane) & 63] = (float)run;
+                mix = 0;
+            }
+        }
     }
     __syncthreads();
     // coalesced write-out: each wave stores its own 64 x 64 tile, one 256-byte row per instruction
     const int64_t rows = (total_frames + 63) / 64 * 64;
     for (int r = 0; r < 64; ++r) {
         const int64_t f = f0 + r;
-        const float v = lane < n_states ? tile[wave][r][(lane ^ r) & 63] : -INFINITY;
+        const float v = lane < n_states / n_mix ? tile[wave][r][(lane ^ r) & 63] : -INFINITY;
         if (f < rows) ll[f * LSR_LL_STRIDE + lane] = v;
     }
 }
@@ -121,10 +145,10 @@ int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames
     lsr_prof_begin(ctx, LSR_K_EMISSION);
     if (ctx->whiten_triangular)
         hipLaunchKernelGGL((lsr_emission_kernel<4, 8>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
-                           feats_d, total_frames, ctx->d_wfrag, (const v4d*)ctx->d_cfrag, ctx->d_lognorm, ctx->n_states, ll_d);
+                           feats_d, total_frames, ctx->d_wfrag, (const v4d*)ctx->d_cfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
     else
         hipLaunchKernelGGL((lsr_emission_kernel<0, 0>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
-                           feats_d, total_frames, ctx->d_wfrag, (const v4d*)ctx->d_cfrag, ctx->d_lognorm, ctx->n_states, ll_d);
+                           feats_d, total_frames, ctx->d_wfrag, (const v4d*)ctx->d_cfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_emission_kernel");
     return LSR_OK;

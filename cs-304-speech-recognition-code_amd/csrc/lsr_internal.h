@@ -38,6 +38,8 @@ struct lsr_ctx {
     bool whiten_triangular = false;  // every whitening matrix is zero above the diagonal
     double* d_cfrag = nullptr;       // [S][3][64][4]  -(mean U)[j] laid out as the initial MFMA accumulator
     double* d_lognorm = nullptr;     // [S]
+    int n_mix = 1;                   // components per state (n_states counts components)
+    double* d_logw = nullptr;        // [S] log mixture weights (n_mix > 1 only)
 
     // loop graph (device)
     int g_states = 0, g_words = 0, g_silence = -1;

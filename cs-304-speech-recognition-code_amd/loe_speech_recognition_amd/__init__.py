@@ -8,7 +8,7 @@ from .mfcc import MFCC
 from .transition_probability import SparseMatrix, TransitionProbabilities, LogTransitionProbabilities
 from .model_boundary import ModelBoundary
 from .signal import Signal, SortedSignals
-from .hidden_markov_model import (MultivariateNormal, HiddenMarkovModel, HiddenMarkovModelTrainable,
+from .hidden_markov_model import (MultivariateNormal, GaussianMixture, HiddenMarkovModel, HiddenMarkovModelTrainable,
                                   HiddenMarkovModelInference, HiddenMarkovModelMultiWord,
                                   HiddenMarkovModelTrainContinuous)
 from .model_collection import ModelCollection
@@ -16,6 +16,6 @@ from .ti_digits import TI_DIGITS_LABELS
 from . import _native, distributed, synthetic
 
 __all__ = ["MFCC", "SparseMatrix", "TransitionProbabilities", "LogTransitionProbabilities", "ModelBoundary", "Signal",
-           "SortedSignals", "MultivariateNormal", "HiddenMarkovModel", "HiddenMarkovModelTrainable",
+           "SortedSignals", "MultivariateNormal", "GaussianMixture", "HiddenMarkovModel", "HiddenMarkovModelTrainable",
            "HiddenMarkovModelInference", "HiddenMarkovModelMultiWord", "HiddenMarkovModelTrainContinuous",
            "ModelCollection", "TI_DIGITS_LABELS"]

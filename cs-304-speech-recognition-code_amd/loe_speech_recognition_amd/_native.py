@@ -51,6 +51,7 @@ def _declare(lib) -> None:
         "lsr_host_mel_filterbank": (None, [POINTER(c_float)]),
         "lsr_host_dct_matrix": (None, [POINTER(c_double)]),
         "lsr_model_upload": (c_int, [P, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+        "lsr_model_set_mixtures": (c_int, [P, c_int, POINTER(c_double)]),
         "lsr_loop_graph_upload": (c_int, [P, c_int, c_int, POINTER(c_float), POINTER(c_int32), POINTER(c_int32), c_int]),
         "lsr_loop_set_between": (c_int, [P, c_double, c_int]),
         "lsr_mfcc_batch": (c_int, [P, P, P, P, c_int, c_int64, P]),
@@ -75,7 +76,7 @@ EXPORTED_SYMBOLS = [
     "lsr_host_mel_filterbank", "lsr_host_dct_matrix", "lsr_model_upload", "lsr_loop_graph_upload",
     "lsr_loop_set_between", "lsr_mfcc_batch", "lsr_emission_batch", "lsr_decode_loop_batch",
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
-    "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16",
+    "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures",
 ]
 
 
@@ -236,7 +237,7 @@ class Engine:
 
     # -- model / graph ----------------------------------------------------------------------------
     def set_model(self, token, mean: np.ndarray, whiten: np.ndarray, log_norm: np.ndarray,
-                  triangular: Optional[bool] = None) -> None:
+                  log_weights: Optional[np.ndarray] = None, n_mix: int = 1, triangular: Optional[bool] = None) -> None:
         """Upload stacked Gaussians.  By default the whitening matrices are first rotated to lower
         triangular form: U^T = Q R gives L = R^T with L L^T = U U^T, so |(x - mu) L|^2 is the same
         Mahalanobis distance (an orthogonal change of basis of the whitened vector) while the
@@ -256,8 +257,12 @@ class Engine:
         dp = POINTER(c_double)
         self._check(self.lib.lsr_model_upload(self.ctx, S, mean.ctypes.data_as(dp), whiten.ctypes.data_as(dp),
                                               log_norm.ctypes.data_as(dp)))
+        if n_mix > 1:
+            lw = np.ascontiguousarray(log_weights, dtype=np.float64)
+            assert lw.shape == (S,) and S % n_mix == 0
+            self._check(self.lib.lsr_model_set_mixtures(self.ctx, n_mix, lw.ctypes.data_as(dp)))
         self._model_token = token
-        self.n_model_states = S
+        self.n_model_states = S // n_mix
 
     def set_loop_graph(self, token, band: np.ndarray, lower: Sequence[int], upper: Sequence[int], silence_word: int) -> None:
         if token is not None and token == self._graph_token:

@@ -72,16 +72,61 @@ class MultivariateNormal:
     def log_pdf(self, x: np.ndarray) -> np.float32:
         assert x.shape[0] == self.dim_of_features
         eng = _native.get_engine()
-        eng.set_model(None, self.mean[None], self.whiten[None], np.array([self.log_norm]))
+        eng.set_model(None, self.mean[None], self.whiten[None], np.array([self.log_norm]))   # single Gaussian
         fb = eng.feature_batch([np.asarray(x, dtype=np.float32)[None, :]])
         return eng.emission(fb)[0, 0].cpu().numpy()[()]
 
 
-def stack_gaussians(gaussians: Sequence[MultivariateNormal]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    mean = np.stack([g.mean for g in gaussians])
-    whiten = np.stack([g.whiten for g in gaussians])
-    log_norm = np.array([g.log_norm for g in gaussians], dtype=np.float64)
-    return mean, whiten, log_norm
+@dataclass
+class GaussianMixture:
+    """State emission with M weighted full-covariance components: log sum_m w_m N(x; mu_m, Sigma_m),
+    accumulated with np.logaddexp semantics in float64 like HMM_GMM.log_emission_prob of the
+    reference's retired GMM code (deprecated/gaussian_mixture_model.py:159-164), rounded to float32
+    like the live MultivariateNormal.  Can stand wherever a MultivariateNormal stands in a model's
+    ``_multivariate_normals`` list (all states of a model set must use the same M)."""
+    weights: np.ndarray
+    components: List[MultivariateNormal]
+
+    @classmethod
+    def from_weights_means_covariances(cls, weights, means, covariances) -> "GaussianMixture":
+        comps = [MultivariateNormal.from_means_covariances(m, c) for m, c in zip(means, covariances)]
+        w = np.asarray(weights, dtype=np.float64)
+        assert w.shape == (len(comps),)
+        return cls(w, comps)
+
+    @property
+    def dim_of_features(self) -> int:
+        return self.components[0].dim_of_features
+
+    def log_pdf(self, x: np.ndarray) -> np.float32:
+        assert x.shape[0] == self.dim_of_features
+        eng = _native.get_engine()
+        eng.set_model(None, *stack_gaussians([self]))
+        fb = eng.feature_batch([np.asarray(x, dtype=np.float32)[None, :]])
+        return eng.emission(fb)[0, 0].cpu().numpy()[()]
+
+
+def stack_gaussians(gaussians: Sequence) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Optional[np.ndarray], int]:
+    """Flat float64 arrays for lsr_model_upload: (mean, whiten, log_norm, log_weights, n_mix).
+    Mixtures contribute their components consecutively."""
+    n_mix = {len(g.components) if isinstance(g, GaussianMixture) else 1 for g in gaussians}
+    if len(n_mix) != 1:
+        raise ValueError("all states must have the same number of mixture components")
+    n_mix = n_mix.pop()
+    flat: List[MultivariateNormal] = []
+    logw: List[float] = []
+    for g in gaussians:
+        if isinstance(g, GaussianMixture):
+            flat.extend(g.components)
+            with np.errstate(divide="ignore"):
+                logw.extend(np.log(g.weights))
+        else:
+            flat.append(g)
+            logw.append(0.0)
+    mean = np.stack([g.mean for g in flat])
+    whiten = np.stack([g.whiten for g in flat])
+    log_norm = np.array([g.log_norm for g in flat], dtype=np.float64)
+    return mean, whiten, log_norm, (np.array(logw, dtype=np.float64) if n_mix > 1 else None), n_mix
 
 
 @dataclass
@@ -156,10 +201,14 @@ class HiddenMarkovModel:
 
     # -- persistence (flat arrays instead of the reference's pickled SciPy objects) -----------------
     def _arrays_to_save(self) -> Dict[str, np.ndarray]:
-        mean, whiten, _ = stack_gaussians(self._multivariate_normals)
-        return {"label": np.array(self.label), "mean": mean, "whiten": whiten,
-                "log_pdet": np.array([g.log_pdet for g in self._multivariate_normals]),
-                "log_trans": self._log_transition_probs.to_array()}
+        mean, whiten, _, log_weights, n_mix = stack_gaussians(self._multivariate_normals)
+        comps = [c for g in self._multivariate_normals for c in (g.components if isinstance(g, GaussianMixture) else [g])]
+        out = {"label": np.array(self.label), "mean": mean, "whiten": whiten,
+               "log_pdet": np.array([g.log_pdet for g in comps]),
+               "log_trans": self._log_transition_probs.to_array()}
+        if n_mix > 1:
+            out["mixture_weights"] = np.exp(log_weights).reshape(-1, n_mix)
+        return out
 
     def save(self, parent_folder_path: str = "./cache") -> None:
         folder = os.path.join(parent_folder_path, f"{self.label}")
@@ -176,11 +225,16 @@ class HiddenMarkovModel:
         return model
 
     def _load_arrays(self, z) -> None:
-        self._multivariate_normals = []
+        comps = []
         for mean, whiten, log_pdet in zip(z["mean"], z["whiten"], z["log_pdet"]):
             g = MultivariateNormal()
             g.mean, g.whiten, g.log_pdet, g.dim_of_features = mean, whiten, float(log_pdet), mean.shape[0]
-            self._multivariate_normals.append(g)
+            comps.append(g)
+        if "mixture_weights" in z.files:
+            w = z["mixture_weights"]
+            m = w.shape[1]
+            comps = [GaussianMixture(w[i], comps[i * m:(i + 1) * m]) for i in range(w.shape[0])]
+        self._multivariate_normals = comps
         dense = z["log_trans"]
         ltp = LogTransitionProbabilities(dense.shape[0])
         for i in range(dense.shape[0]):

@@ -83,6 +83,14 @@ void lsr_host_dct_matrix(double* out13x40);           /* DCT-II, orthonormal, fi
 int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, const double* whiten,
                      const double* log_norm);
 
+/* Gaussian-mixture emissions: regroup the uploaded Gaussians as n_states / n_mix states of n_mix
+ * consecutive components with log_weights[n_states] (host, float64).  Emission scores become
+ * float32(logaddexp over the components of log w + log N), accumulated sequentially in float64
+ * like HMM_GMM.log_emission_prob of the reference's retired GMM code
+ * (deprecated/gaussian_mixture_model.py:159-164).  n_mix = 1 restores single Gaussians; a new
+ * lsr_model_upload resets to 1. */
+int lsr_model_set_mixtures(lsr_ctx* ctx, int n_mix, const double* log_weights);
+
 /* Replaces the state space built by HiddenMarkovModelInference.from_folder
  * (hidden_markov_model.py:421-456): word models stacked in order, band[d][s] =
  * log a(s-d -> s) for d = 0,1,2 (-inf where s-d is not a candidate predecessor: before the

@@ -104,6 +104,42 @@ def emission_fast(x: np.ndarray, means64: np.ndarray, U: np.ndarray, logdet: np.
     return np.ascontiguousarray(ll.T).astype(np.float32)
 
 
+def emission_gmm_ref(x: np.ndarray, weights: np.ndarray, gaussians: Sequence[Sequence[GaussianRef]]) -> np.ndarray:
+    """Mixture emissions the way the reference's retired GMM code forms them
+    (deprecated/gaussian_mixture_model.py:159-164): log_prob = -inf, then
+    log_prob = np.logaddexp(log_prob, np.log(w_m) + logpdf_m(x)) component by component in
+    float64; rounded to float32 like the live code's MultivariateNormal.log_pdf.
+    PARITY UNPINNED: that module is dead code (not importable: it imports a function that does
+    not exist and runs a script at import), so no reference output exists for it."""
+    T = x.shape[0]
+    out = np.empty((T, len(gaussians)), dtype=np.float32)
+    with np.errstate(divide="ignore"):
+        for t in range(T):
+            for s, comps in enumerate(gaussians):
+                lp = -float("inf")
+                for m, g in enumerate(comps):
+                    lp = np.logaddexp(lp, np.log(weights[s][m]) + g.frozen.logpdf(x[t]))
+                out[t, s] = lp
+    return out
+
+
+def emission_gmm_fast(x: np.ndarray, weights: np.ndarray, gaussians: Sequence[Sequence[GaussianRef]]) -> np.ndarray:
+    """Vectorised restatement of ``emission_gmm_ref`` (same sequential logaddexp order)."""
+    S, M = len(gaussians), len(gaussians[0])
+    mu, U, ld = export_gaussians([g for comps in gaussians for g in comps])
+    x64 = np.asarray(x, dtype=np.float64)
+    D = x64.shape[1]
+    dev = x64[None] - mu[:, None, :]
+    maha = np.sum(np.square(np.matmul(dev, U)), axis=-1)
+    lp = (-0.5 * ((D * LOG_2PI + ld)[:, None] + maha)).reshape(S, M, -1)
+    with np.errstate(divide="ignore"):
+        lw = np.log(np.asarray(weights, dtype=np.float64))
+    acc = np.full((S, x64.shape[0]), -np.inf)
+    for m in range(M):
+        acc = np.logaddexp(acc, lw[:, m, None] + lp[:, m])
+    return np.ascontiguousarray(acc.T).astype(np.float32)
+
+
 # ----------------------------------------------------------------------------
 # Sparse log-transition store  (transition_probability.py:11-82)
 # ----------------------------------------------------------------------------

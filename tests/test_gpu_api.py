@@ -192,3 +192,68 @@ def test_continuous_iteration_on_synthetic_speech_matches_oracle(words):
         assert trans_close(t._transition_probs.to_array(), ref[lab].trans), lab
     # train() drives the same iteration and stops on convergence or after max_iterations
     tc.train(labeled, max_iterations=2)
+
+
+@pytest.mark.parametrize("n_mix", [2, 4])
+def test_gaussian_mixture_emissions_and_decode(n_mix):
+    """Mixture emissions (log-sum over components) against the oracle's restatement of
+    deprecated/gaussian_mixture_model.py:159-164, and a loop decode that uses them."""
+    from loe_speech_recognition_amd import (GaussianMixture, HiddenMarkovModel, HiddenMarkovModelInference,
+                                            LogTransitionProbabilities, TransitionProbabilities, _native)
+    from loe_speech_recognition_amd.hidden_markov_model import stack_gaussians
+
+    rng = np.random.default_rng(40 + n_mix)
+    labels = ["1", "2", "S"]
+    sizes = [5, 5, 3]
+    weights, o_comps, mixtures = [], [], []
+    for _ in range(sum(sizes)):
+        w = rng.dirichlet(np.ones(n_mix) * 2)
+        if len(weights) == 3:
+            w = np.concatenate([[0.0], w[1:] / w[1:].sum()])           # a zero weight: log w = -inf
+        means = (rng.standard_normal((n_mix, 39)) * 2).astype(np.float32)
+        cov = np.stack([(lambda a: a @ a.T / 39 + 1e-2 * np.eye(39))(rng.standard_normal((39, 39))) for _ in range(n_mix)]).astype(np.float32)
+        weights.append(w)
+        o_comps.append([O.GaussianRef(m, c) for m, c in zip(means, cov)])
+        mixtures.append(GaussianMixture.from_weights_means_covariances(w, means, cov))
+    x = (rng.standard_normal((150, 39)) * 2).astype(np.float32)
+    eng = _native.get_engine()
+    eng.set_model(None, *stack_gaussians(mixtures))
+    got = eng.emission(eng.feature_batch([x])).cpu().numpy()[:150, :13]
+    ref = O.emission_gmm_fast(x, np.array(weights), o_comps)
+    assert rel_err(got, ref) <= 1e-4
+    assert np.all(np.abs(got - ref) <= 2 * np.spacing(np.abs(ref)))
+    assert np.mean(got != ref) < 0.02
+    slow = O.emission_gmm_ref(x[:3], np.array(weights), o_comps)
+    assert np.all(np.abs(got[:3] - slow) <= 2 * np.spacing(np.abs(slow)))
+    v = mixtures[5].log_pdf(x[7])
+    assert v.dtype == np.float32 and abs(v - ref[7, 5]) <= 2 * np.spacing(abs(ref[7, 5]))
+    # decode with mixture states: the recursion sees the same float32 scores as the oracle recursion
+    models, at = [], 0
+    trans = {}
+    for lab, n in zip(labels, sizes):
+        t = np.zeros((n, n), np.float32)
+        for s in range(n):
+            w = rng.uniform(0.2, 1, size=min(3, n - s))
+            t[s, s:s + len(w)] = w / w.sum()
+        trans[lab] = t
+        m = HiddenMarkovModel(lab)
+        m._multivariate_normals = mixtures[at:at + n]
+        m._log_transition_probs = LogTransitionProbabilities.from_transition_probability(
+            TransitionProbabilities.from_transition_probability(t))
+        models.append(m)
+        at += n
+    inf = HiddenMarkovModelInference.from_models(models)
+    inf._log_transition_probability_between_words = -20
+    score, path = inf._viterbi(x)
+    ltp = O.LogTransRef()
+    for lab in labels:
+        ltp.append(O.LogTransRef.from_probs(trans[lab]))
+    bounds = O.BoundariesRef(sizes, labels)
+    band = O.band_from_ltp(ltp, 13, [bounds.find_lower(s) for s in range(13)])
+    s_ref, p_ref = O.viterbi_loop_fast(got, band, bounds.lower, bounds.upper, -20)
+    assert score == s_ref and np.array_equal(path, p_ref)
+    assert inf.predict(x) == "".join(bounds.get_labels(p_ref))
+    # chain decode and persistence keep the mixtures
+    one = models[0].predict(x[:40])
+    s1, p1, _ = O.viterbi_chain_fast(got[:40, :5], O.band_from_ltp(O.LogTransRef.from_probs(trans["1"]), 5))
+    assert one[0] == s1 and np.array_equal(one[1], p1)

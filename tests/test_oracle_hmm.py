@@ -176,3 +176,34 @@ def test_g6_isolated_classifier_tie_order(golden_dir):
         assert O.classify_isolated(models, x) == preds[i]
         scores = np.array([m.align_fast(x)[0] for m in models], dtype=np.float32)
         assert np.array_equal(scores, g[f"scores{i}"])
+
+
+def _random_gmm(rng, n_states, n_mix):
+    weights = rng.dirichlet(np.ones(n_mix) * 2, size=n_states)
+    comps = []
+    for _ in range(n_states):
+        row = []
+        for _ in range(n_mix):
+            a = rng.standard_normal((39, 39))
+            row.append(O.GaussianRef((rng.standard_normal(39) * 2).astype(np.float32),
+                                     (a @ a.T / 39 + 1e-2 * np.eye(39)).astype(np.float32)))
+        comps.append(row)
+    return weights, comps
+
+
+def test_gmm_emission_restatements_agree():
+    """Mixture emissions have no reference output (dead code upstream): check the restatement against
+    the definition log sum_m w_m N_m and its vectorised form against the loop form."""
+    rng = np.random.default_rng(8)
+    weights, comps = _random_gmm(rng, 3, 4)
+    x = (rng.standard_normal((6, 39)) * 2).astype(np.float32)
+    ref = O.emission_gmm_ref(x, weights, comps)
+    from scipy.special import logsumexp
+
+    direct = np.array([[logsumexp([np.log(weights[s][m]) + comps[s][m].frozen.logpdf(x[t]) for m in range(4)])
+                        for s in range(3)] for t in range(6)])
+    assert np.allclose(ref, direct, rtol=1e-6)
+    fast = O.emission_gmm_fast(x, weights, comps)
+    assert np.all(np.abs(fast - ref) <= np.spacing(np.abs(ref)))
+    one = O.emission_gmm_ref(x, np.ones((3, 1)), [[c[0]] for c in comps])
+    assert np.array_equal(one, O.emission_ref(x, [c[0] for c in comps]))
