@@ -47,16 +47,48 @@ struct vit_args {
     int path_cap;      // bytes reserved for the path in LDS (multiple of 64)
 };
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
+// Cross-lane moves through the DPP path of the vector ALU (no LDS round trip).  CTRL: 0x111..0x11F
+// row_shr:1..15 (within rows of 16 lanes), 0x138 wave_shr:1, 0x142 row_bcast:15, 0x143 row_bcast:31.
+// Lanes without a source keep `fill`.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp(float fill, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
 }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp(double fill, double v) {
+    const long long f = __builtin_bit_cast(long long, fill), x = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)x, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(x >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ float lane63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ double lane63(double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)x, 63), hi = __builtin_amdgcn_readlane((int)(x >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double vmax(double a, double b) { return fmax(a, b); }
+
+// maximum over the 64 lanes, returned to every lane: inclusive max-scan inside each row of 16,
+// row totals carried to the next rows, grand total read from lane 63
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+    const T ninf = (T)(-INFINITY);
+    v = vmax(v, dpp<0x111>(ninf, v));
+    v = vmax(v, dpp<0x112>(ninf, v));
+    v = vmax(v, dpp<0x114>(ninf, v));
+    v = vmax(v, dpp<0x118>(ninf, v));
+    v = vmax(v, dpp<0x142, 0xA>(ninf, v));
+    v = vmax(v, dpp<0x143, 0xC>(ninf, v));
+    return lane63(v);
 }
 
 template <int MODE>
@@ -119,8 +151,8 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
             if (t < T) {
                 const float e = ebuf[i];
                 if (t + VIT_PREFETCH < T) ebuf[i] = llrow[(int64_t)(t + VIT_PREFETCH) * LSR_LL_STRIDE];
-                const float p1 = __shfl_up(prev, 1);
-                const float p2 = __shfl_up(prev, 2);
+                const float p1 = dpp<0x138>(-INFINITY, prev);      // prev of lane - 1
+                const float p2 = dpp<0x138>(-INFINITY, p1);        // prev of lane - 2
                 const float v0 = a0 + prev, v1 = a1 + p1, v2 = a2 + p2;
                 float best = fmaxf(fmaxf(v2, v1), v0);
                 int ptr = (v2 == best) ? lane - 2 : ((v1 == best) ? lane - 1 : lane);
