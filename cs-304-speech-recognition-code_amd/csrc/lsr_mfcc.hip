@@ -35,10 +35,10 @@ __device__ __forceinline__ void dft5(const cplx x0, const cplx x1, const cplx x2
     const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;    // sin(2pi/5), sin(4pi/5)
     const cplx t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
     X[0] = {x0.re + t1.re + t2.re, x0.im + t1.im + t2.im};
-    const cplx m1 = {x0.re + c1 * t1.re + c2 * t2.re, x0.im + c1 * t1.im + c2 * t2.im};
-    const cplx m2 = {x0.re + c2 * t1.re + c1 * t2.re, x0.im + c2 * t1.im + c1 * t2.im};
-    const cplx n1 = {s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im};
-    const cplx n2 = {s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im};
+    const cplx m1 = {fma(c2, t2.re, fma(c1, t1.re, x0.re)), fma(c2, t2.im, fma(c1, t1.im, x0.im))};
+    const cplx m2 = {fma(c1, t2.re, fma(c2, t1.re, x0.re)), fma(c1, t2.im, fma(c2, t1.im, x0.im))};
+    const cplx n1 = {fma(s2, t4.re, s1 * t3.re), fma(s2, t4.im, s1 * t3.im)};
+    const cplx n2 = {fma(-s1, t4.re, s2 * t3.re), fma(-s1, t4.im, s2 * t3.im)};
     X[1] = cadd(m1, cmul_negi(n1));
     X[4] = cadd(m1, cmul_posi(n1));
     X[2] = cadd(m2, cmul_negi(n2));
