@@ -123,6 +123,12 @@ __global__ void lsr_utt_index_kernel(const int64_t* __restrict__ frame_off, int3
     for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) frame_utt[f] = b;
 }
 
+int lsr_launch_utt_index(lsr_ctx* ctx, const int64_t* off_d, int n_utts, int32_t* out_d) {
+    hipLaunchKernelGGL(lsr_utt_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, off_d, out_d);
+    LSR_LAUNCH_CHECK(ctx, "lsr_utt_index_kernel");
+    return LSR_OK;
+}
+
 __global__ __launch_bounds__(256) void lsr_remux_kernel(const int8_t* __restrict__ paths,
                                                         const int64_t* __restrict__ frame_off,
                                                         const int64_t* __restrict__ chain_off,

@@ -13,9 +13,10 @@ from .hidden_markov_model import (MultivariateNormal, GaussianMixture, HiddenMar
                                   HiddenMarkovModelTrainContinuous)
 from .model_collection import ModelCollection
 from .ti_digits import TI_DIGITS_LABELS
+from .signal_separation import SignalSeparation
 from . import _native, distributed, synthetic
 
 __all__ = ["MFCC", "SparseMatrix", "TransitionProbabilities", "LogTransitionProbabilities", "ModelBoundary", "Signal",
            "SortedSignals", "MultivariateNormal", "GaussianMixture", "HiddenMarkovModel", "HiddenMarkovModelTrainable",
            "HiddenMarkovModelInference", "HiddenMarkovModelMultiWord", "HiddenMarkovModelTrainContinuous",
-           "ModelCollection", "TI_DIGITS_LABELS"]
+           "ModelCollection", "TI_DIGITS_LABELS", "SignalSeparation"]

@@ -20,7 +20,8 @@ LL_STRIDE = 64
 HOP = 160
 N_FFT = 320
 MIN_FRAMES = 9          # the width-9 delta filter needs 9 frames (librosa raises below that)
-KERNEL_IDS = {"frame_index": 0, "mel_power": 1, "mfcc_finish": 2, "emission": 3, "viterbi": 4, "stats": 5}
+KERNEL_IDS = {"frame_index": 0, "mel_power": 1, "mfcc_finish": 2, "emission": 3, "viterbi": 4, "stats": 5,
+              "separation": 6}
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "liblsr_hip.so"))
@@ -63,6 +64,9 @@ def _declare(lib) -> None:
         "lsr_decode_chain_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, c_int64, P, P, P, P, P, P]),
         "lsr_accumulate_stats": (c_int, [P, P, P, c_int64, c_int, P, P, P]),
         "lsr_remux_slots": (c_int, [P, P, P, P, P, P, c_int, c_int64, c_int, c_int, P, P]),
+        "lsr_separation_scan": (c_int, [P, P, c_int, P, P, c_int, c_int64, c_int, c_double, c_double, c_int, c_int,
+                                        P, P, P, P, P, P]),
+        "lsr_gather_segments": (c_int, [P, P, c_int, P, P, c_int, c_int64, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not export a declared symbol
@@ -76,7 +80,8 @@ EXPORTED_SYMBOLS = [
     "lsr_host_mel_filterbank", "lsr_host_dct_matrix", "lsr_model_upload", "lsr_loop_graph_upload",
     "lsr_loop_set_between", "lsr_mfcc_batch", "lsr_emission_batch", "lsr_decode_loop_batch",
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
-    "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures",
+    "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures", "lsr_separation_scan",
+    "lsr_gather_segments",
 ]
 
 
@@ -366,6 +371,56 @@ class Engine:
         self._check(self.lib.lsr_accumulate_stats(self.ctx, self._ptr(fb_feats), self._ptr(slots), total_frames, n_slots,
                                                   self._ptr(count), self._ptr(sum_x), self._ptr(sum_xx)))
         return count, sum_x, sum_xx
+
+    # -- silence stripping ------------------------------------------------------------------------
+    def separation_scan(self, signals: Sequence[np.ndarray], frame_size: int, high: float, low: float,
+                        max_silence_frames: int, min_kept_frames: int = 9, want_energy: bool = False) -> dict:
+        """Two-threshold scan of every clip.  Returns host arrays first/end/status int32[B],
+        noise uint8[total scan frames], scan_off int64[B+1], sample_off int64[B+1] (+ energy
+        float32 when asked) and the device audio buffer for gather_segments."""
+        if len(signals) == 0:
+            raise ValueError("empty batch")
+        t = self.torch
+        n = np.array([s.shape[0] for s in signals], dtype=np.int64)
+        if n.min() < 1:
+            raise ValueError("zero-size array to reduction operation maximum which has no identity")
+        dtype = np.int16 if all(s.dtype == np.int16 for s in signals) else np.float32
+        flat = np.concatenate([np.asarray(s, dtype=dtype) for s in signals])
+        soff = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        scan_off = np.concatenate([[0], np.cumsum(n // frame_size + 1)]).astype(np.int64)
+        total = int(scan_off[-1])
+        B = n.shape[0]
+        d_audio, d_soff, d_scan = self.to_device(flat), self.to_device(soff), self.to_device(scan_off)
+        first, end, status = (self.empty((B,), t.int32) for _ in range(3))
+        noise = self.empty((total,), t.uint8)
+        energy = self.empty((total,), t.float32) if want_energy else None
+        volume = self.empty((B,), t.float32)
+        self._check(self.lib.lsr_separation_scan(self.ctx, self._ptr(d_audio), 1 if dtype == np.int16 else 0,
+                                                 self._ptr(d_soff), self._ptr(d_scan), B, total, int(frame_size),
+                                                 float(high), float(low), int(max_silence_frames), int(min_kept_frames),
+                                                 self._ptr(first), self._ptr(end), self._ptr(status), self._ptr(noise),
+                                                 self._ptr(energy), self._ptr(volume)))
+        out = {"first": first.cpu().numpy(), "end": end.cpu().numpy(), "status": status.cpu().numpy(),
+               "noise": noise.cpu().numpy(), "max_volume": volume.cpu().numpy(), "scan_off": scan_off,
+               "sample_off": soff, "audio": d_audio}
+        if want_energy:
+            out["energy"] = energy.cpu().numpy()
+        return out
+
+    def gather_segments(self, src, src_start: np.ndarray, lengths: np.ndarray):
+        """Device concatenation of slices src[src_start[i] : src_start[i] + lengths[i]]."""
+        lengths = np.asarray(lengths, dtype=np.int64)
+        src_start = np.ascontiguousarray(src_start, dtype=np.int64)
+        if lengths.shape[0] == 0 or lengths.min() < 0 or src_start.min() < 0 or \
+                int((src_start + lengths).max()) > src.shape[0]:
+            raise ValueError("segments outside the source buffer")
+        dst_off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        dst = self.empty((int(dst_off[-1]),), src.dtype)
+        d_start, d_off = self.to_device(src_start), self.to_device(dst_off)
+        self._check(self.lib.lsr_gather_segments(self.ctx, self._ptr(src), src.element_size(), self._ptr(d_start),
+                                                 self._ptr(d_off), lengths.shape[0], int(lengths.max()), self._ptr(dst)))
+        self.synchronize()     # the offset arrays above must outlive the kernel
+        return dst, dst_off
 
 
 _engine: Optional[Engine] = None

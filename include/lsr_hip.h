@@ -55,7 +55,8 @@ typedef struct lsr_ctx lsr_ctx;
 #define LSR_K_EMISSION 3
 #define LSR_K_VITERBI 4
 #define LSR_K_STATS 5
-#define LSR_K_COUNT 6
+#define LSR_K_SEPARATION 6
+#define LSR_K_COUNT 7
 
 /* ---- context ---------------------------------------------------------------------------- */
 int lsr_ctx_create(int device, lsr_ctx** out);
@@ -188,6 +189,35 @@ int lsr_remux_slots(lsr_ctx* ctx, const int8_t* paths_d, const int64_t* frame_of
                     const int64_t* chain_off_d, const int32_t* chain_state_d,
                     const int32_t* chain_word_d, int n_utts, int64_t total_frames, int n_states,
                     int drop_last_run, int32_t* slots_d, int64_t* trans_d);
+
+/* ---- silence stripping ------------------------------------------------------------------- */
+/* Replaces the per-clip scan of SignalSeparation._remove_empty / .detect_speech
+ * (signal_separation.py:102-164) for a batch of clips.  A clip of N samples has
+ * N / frame_size full scan frames plus one trailing frame with the remaining samples (possibly
+ * none: its energy is NaN and it counts as a frame without speech, as in the reference);
+ * scan_off_d int64[B+1] are the prefix sums of those counts.  Frame energy is the float32 mean
+ * of |x| rounded exactly as NumPy's float32 mean; thresholds are high * max|clip| and
+ * low * max|clip| (doubles, rounded to float32 for the comparison like NumPy does with a Python
+ * float).  Outputs per clip: first_d (first kept frame, -1 if speech never starts), end_d (the
+ * frame that tripped the silence counter; kept samples are frames [first, end); -1 if it never
+ * tripped) and status_d: 0 = kept, 1 = never tripped (the reference raises FailToProcess,
+ * :99-100), 2 = fewer than min_kept_frames kept frames (:95-97, 9 in the reference).
+ * noise_d uint8[total_scan_frames] flags the frames the reference appends to its noise pool
+ * (:139).  Optional outputs (may be NULL): energy_d float32[total_scan_frames],
+ * max_volume_d float32[B].  frame_size is limited to 256 samples (LSR_ERR_LIMIT beyond). */
+int lsr_separation_scan(lsr_ctx* ctx, const void* audio_d, int audio_is_i16,
+                        const int64_t* sample_off_d, const int64_t* scan_off_d, int n_utts,
+                        int64_t total_scan_frames, int frame_size, double high, double low,
+                        int max_silence_frames, int min_kept_frames, int32_t* first_d,
+                        int32_t* end_d, int32_t* status_d, uint8_t* noise_d, float* energy_d,
+                        float* max_volume_d);
+
+/* Device-side np.concatenate of slices (signal_separation.py:92-94 builds the kept clip and the
+ * noise clip that way): segment i copies dst_off_d[i+1] - dst_off_d[i] elements of elem_bytes
+ * (2 or 4) from src_d + src_start_d[i] to dst_d + dst_off_d[i].  max_segment is the longest
+ * segment (sizes the launch). */
+int lsr_gather_segments(lsr_ctx* ctx, const void* src_d, int elem_bytes, const int64_t* src_start_d,
+                        const int64_t* dst_off_d, int n_segments, int64_t max_segment, void* dst_d);
 
 #ifdef __cplusplus
 }
