@@ -466,6 +466,42 @@ extern "C" int lsr_decode_loop_batch(lsr_ctx* ctx, const float* feats_d, const i
                                    scores_d, paths_d, labels_d, n_labels_d, label_cap);
 }
 
+extern "C" int lsr_decode_loop_sweep(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d, int n_utts,
+                                     int64_t total_frames, int max_frames, const double* between,
+                                     const int32_t* between_is_f64, int n_between, float* scores_d, uint8_t* labels_d,
+                                     int32_t* n_labels_d, int label_cap) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!feats_d || !frame_off_d || !between || !between_is_f64 || !labels_d || !n_labels_d)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_sweep: null pointer");
+    if (n_between < 1 || label_cap < 1 || max_frames < 1)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_sweep: bad sizes");
+    for (int i = 0; i < n_between; ++i)
+        if (between[i] != between[i]) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_sweep: NaN penalty");
+    if (ctx->n_states == 0 || ctx->g_states == 0)
+        return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_loop_sweep: model and loop graph must be uploaded first");
+    if (ctx->n_states / ctx->n_mix != ctx->g_states)
+        return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_loop_sweep: model has %d states, graph %d",
+                        ctx->n_states / ctx->n_mix, ctx->g_states);
+    int rc = check_batch(ctx, "lsr_decode_loop_sweep", n_utts, total_frames);
+    if (rc) return rc;
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(total_frames), "emission scores"))) return rc;
+    if ((rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr))) return rc;
+    const double saved = ctx->between;
+    const int saved_wide = ctx->between_is_f64;
+    for (int i = 0; i < n_between && rc == LSR_OK; ++i) {
+        ctx->between = between[i];
+        ctx->between_is_f64 = between_is_f64[i] != 0;
+        rc = lsr_launch_viterbi_loop(ctx, (const float*)ctx->ws_ll.ptr, frame_off_d, n_utts, total_frames, max_frames,
+                                     scores_d ? scores_d + (size_t)i * n_utts : nullptr, nullptr,
+                                     labels_d + (size_t)i * n_utts * label_cap, n_labels_d + (size_t)i * n_utts,
+                                     label_cap);
+    }
+    ctx->between = saved;
+    ctx->between_is_f64 = saved_wide;
+    return rc;
+}
+
 static int recognize_any(lsr_ctx* ctx, const void* audio_d, int is_i16, const int64_t* sample_off_d,
                          const int64_t* frame_off_d, int n_utts, int64_t total_frames, int max_frames,
                          float* scores_d, int8_t* paths_d, uint8_t* labels_d, int32_t* n_labels_d, int label_cap) {

@@ -60,6 +60,8 @@ def _declare(lib) -> None:
         "lsr_recognize_batch_i16": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
         "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
+        "lsr_decode_loop_sweep": (c_int, [P, P, P, c_int, c_int64, c_int, POINTER(c_double), POINTER(c_int32), c_int,
+                                          P, P, P, c_int]),
         "lsr_recognize_batch": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_decode_chain_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, c_int64, P, P, P, P, P, P]),
         "lsr_accumulate_stats": (c_int, [P, P, P, c_int64, c_int, P, P, P]),
@@ -81,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "lsr_loop_set_between", "lsr_mfcc_batch", "lsr_emission_batch", "lsr_decode_loop_batch",
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
     "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures", "lsr_separation_scan",
-    "lsr_gather_segments",
+    "lsr_gather_segments", "lsr_decode_loop_sweep",
 ]
 
 
@@ -306,6 +308,23 @@ class Engine:
                                                    fb.total_frames, fb.max_frames, self._ptr(scores), self._ptr(paths),
                                                    self._ptr(labels), self._ptr(n_labels), label_cap))
         return scores, paths, labels, n_labels
+
+    def decode_loop_sweep(self, fb: FeatureBatch, betweens: Sequence, label_cap: int = 32):
+        """One emission pass, one loop decode per penalty: (scores [n,B], labels [n,B,cap], n_labels [n,B])."""
+        t = self.torch
+        n = len(betweens)
+        if n == 0:
+            raise ValueError("no penalties given")
+        vals = np.array([float(b) for b in betweens], dtype=np.float64)
+        wide = np.array([1 if isinstance(b, np.float64) else 0 for b in betweens], dtype=np.int32)
+        scores = self.empty((n, fb.n), t.float32)
+        labels = self.empty((n, fb.n, label_cap), t.uint8)
+        n_labels = self.empty((n, fb.n), t.int32)
+        self._check(self.lib.lsr_decode_loop_sweep(self.ctx, self._ptr(fb.feats), self._ptr(fb.frame_off), fb.n,
+                                                   fb.total_frames, fb.max_frames, vals.ctypes.data_as(POINTER(c_double)),
+                                                   wide.ctypes.data_as(POINTER(c_int32)), n, self._ptr(scores),
+                                                   self._ptr(labels), self._ptr(n_labels), label_cap))
+        return scores, labels, n_labels
 
     def recognize(self, ab: AudioBatch, want_paths: bool = False, label_cap: int = 32, out=None):
         t = self.torch

@@ -484,6 +484,31 @@ class HiddenMarkovModelInference:
         _, _, labels, n_labels = eng.decode_loop(fb, want_paths=False, label_cap=label_cap)
         return self._labels_from_device(eng, fb, labels, n_labels, label_cap)
 
+    def predict_sweep(self, signals, betweens: Sequence, label_cap: int = 32) -> List[List[str]]:
+        """Label strings of every utterance for every candidate between-word log-probability — the loop of
+        scripts/project5_find_trans_ndigits_with_sil.py:71-88, which re-decodes the same utterances after
+        assigning ``_log_transition_probability_between_words`` — with the emission scores computed once.
+        ``out[i][b]`` is what ``predict(signals[b])`` returns with the penalty set to ``betweens[i]``."""
+        eng = self._bind()
+        fb = signals if isinstance(signals, _native.FeatureBatch) else eng.feature_batch(signals)
+        if fb.lengths.min() < 2:
+            raise Exception("Failed to find lower boundary for state -1")
+        _, labels, n_labels = eng.decode_loop_sweep(fb, betweens, label_cap=label_cap)
+        names = self._model_boundaries._labels
+        lab, cnt = labels.cpu().numpy(), n_labels.cpu().numpy()
+        out = []
+        for i, between in enumerate(betweens):
+            row = ["".join(names[w] for w in lab[i, b, :min(int(cnt[i, b]), label_cap)]) for b in range(fb.n)]
+            if (cnt[i] > label_cap).any():      # more words than a record holds: decode that penalty alone, from paths
+                saved = self._log_transition_probability_between_words
+                self._log_transition_probability_between_words = between
+                try:
+                    row = self.predict_batch(fb, label_cap=label_cap)
+                finally:
+                    self._log_transition_probability_between_words = saved
+            out.append(row)
+        return out
+
     def recognize_audio(self, signals, label_cap: int = 32) -> List[str]:
         """Audio in, label strings out: MFCC + decode without the features leaving the device
         (the per-utterance work of scripts/project5_test_ndigits_with_sil.py:64-77)."""

@@ -165,6 +165,17 @@ int lsr_decode_chain_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* fr
                            const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d,
                            float* final_d);
 
+/* The penalty sweep of scripts/project5_find_trans_ndigits_with_sil.py:71-88 (the same
+ * utterances decoded once per candidate between-word log-probability) as one call: emission scores
+ * are computed once and the loop decoder runs once per entry of between[n_between] (host array;
+ * between_is_f64[i] as in lsr_loop_set_between).  Outputs are laid out [n_between][B]...:
+ * scores_d float32[n_between][B] (may be NULL), labels_d uint8[n_between][B][label_cap],
+ * n_labels_d int32[n_between][B].  The penalty set with lsr_loop_set_between is left unchanged. */
+int lsr_decode_loop_sweep(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d, int n_utts,
+                          int64_t total_frames, int max_frames, const double* between,
+                          const int32_t* between_is_f64, int n_between, float* scores_d,
+                          uint8_t* labels_d, int32_t* n_labels_d, int label_cap);
+
 /* ---- hard-alignment statistics ---------------------------------------------------------- */
 /* Replaces the data reduction of SortedSignals.order_by_state / .transition_probabilities and
  * HiddenMarkovModelTrainable._update_middleware_parameters (signal.py:68-91,

@@ -145,3 +145,29 @@ def test_full_batch_properties(decoder):
             assert ok.all() and p[0] in lower
     acc = np.mean([strings[pos] == truth[src] for pos, src in enumerate(order)])
     assert acc >= 0.95, acc
+
+
+def test_penalty_sweep_equals_one_decode_per_penalty(decoder, oracle_graph):
+    """predict_sweep (one emission pass, one decode per penalty) returns what re-decoding after each
+    assignment of the between-word penalty returns, for int, float and np.float64 penalties, and the
+    penalty left on the object is untouched."""
+    from loe_speech_recognition_amd import MFCC, synthetic
+
+    sigs, _ = synthetic.batch(3, 40, 2)
+    feats = MFCC.batch(sigs, 16000)
+    betweens = [0, -50, -100, -250.5, np.log(0.005), np.float64(-30.0), -2000, np.float32(-75.0), -1e5, 40.0]
+    swept = decoder.predict_sweep(feats, betweens)
+    assert len(swept) == len(betweens)
+    saved = decoder._log_transition_probability_between_words
+    try:
+        for b, row in zip(betweens, swept):
+            decoder._log_transition_probability_between_words = b
+            assert decoder.predict_batch(feats) == row
+            for i in (0, 7, 21):
+                assert oracle_decode(oracle_graph, feats[i], b)[2] == row[i]
+    finally:
+        decoder._log_transition_probability_between_words = saved
+    assert decoder.predict_batch(feats) == swept[2]
+    assert len({tuple(r) for r in swept}) > 1          # the penalty matters on this data
+    with pytest.raises(ValueError):
+        decoder.predict_sweep(feats, [])
