@@ -299,8 +299,9 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     if (n_states < 1 || !mean || !whiten || !log_norm) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_model_upload: bad argument");
     if (n_states > 4096) return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_model_upload: %d states > 4096", n_states);
     const int D = LSR_DIM;
-    std::vector<double> frag((size_t)n_states * LSR_KSTEPS * LSR_JTILES * 64, 0.0);
-    std::vector<double> cinit((size_t)n_states * LSR_JTILES * 64 * 4, 0.0);
+    // one all-zero row tile past the end: the kernel prefetches one tile ahead without a bounds test
+    std::vector<double> frag(((size_t)n_states * LSR_JTILES + 1) * LSR_KSTEPS * 64, 0.0);
+    std::vector<double> cinit(((size_t)n_states * LSR_JTILES + 1) * 64 * 4, 0.0);
     bool triangular = true;          // zero above the diagonal: feature k only feeds components j <= k
     for (int s = 0; s < n_states; ++s) {
         // c[j] = sum_k mean[k] U[k][j] (extended precision, rounded once); lane l, register r of the

@@ -27,6 +27,22 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define EM_WAVES 4
 
+// Exchange the upper 32 lanes of a with the lower 32 lanes of b (v_permlane32_swap), and the odd
+// 16-lane rows of a with the even rows of b (v_permlane16_swap): after the exchange a + b adds
+// lane pairs 32 (16) apart, the first operand's sums landing in the lower (even) half.
+__device__ __forceinline__ void em_swap32(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void em_swap16(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
+}
+
 template <int KB1, int KB2>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
@@ -53,14 +69,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
         }
     }
 
-    const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
-    const double* wf = wfrag + lane;          // [state][row tile][k-step][lane]
-    const v4d* cf = cfrag + lane;             // [state][row tile][lane]: -c for the lane's 4 rows of the C tile
-
+    // [state][row tile][k-step][lane] and [state][row tile][lane] (-c for the lane's 4 rows of the C
+    // tile); both tables end with one zero tile, so the look-ahead below needs no bounds test
     double wc[LSR_KSTEPS], wn[LSR_KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = wf[ks * 64];
-    v4d cc = cf[0], cn;
+    for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = wfrag[ks * 64 + lane];
+    v4d cc = cfrag[lane], cn;
 
     double run = 0.0;          // log-sum of the components of the current state seen so far
     int mix = 0;
@@ -71,14 +85,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
             const int kb = a == 0 ? 0 : (a == 1 ? KB1 : KB2);
             // fetch the fragments of the next row tile (next state after the third tile)
             {
-                const int64_t nxt = (int64_t)s * LSR_JTILES + a + 1;
-                const bool more = nxt < (int64_t)n_states * LSR_JTILES;
-                const double* src = wf + (more ? nxt : 0) * (LSR_KSTEPS * 64);
+                const int nxt = s * LSR_JTILES + a + 1;                      // wave-uniform
+                const double* src = wfrag + (size_t)nxt * (LSR_KSTEPS * 64);
                 const int nkb = a == 0 ? KB1 : (a == 1 ? KB2 : 0);
 #pragma unroll
                 for (int ks = 0; ks < LSR_KSTEPS; ++ks)
-                    if (ks >= nkb) wn[ks] = src[ks * 64];
-                cn = cf[(more ? nxt : 0) * 64];
+                    if (ks >= nkb) wn[ks] = src[ks * 64 + lane];
+                cn = cfrag[(size_t)nxt * 64 + lane];
             }
             v4d acc[4];
 #pragma unroll
@@ -93,22 +106,23 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
                     acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[3][ks], acc[3], 0, 0, 0);
                 }
             }
+            // rows 40..47 (registers 2 and 3 of the third tile) are padding: always zero
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ss[q] = fma(acc[q][r], acc[q][r], ss[q]);
+                for (int r = 0; r < (a == 2 ? 2 : 4); ++r) ss[q] = fma(acc[q][r], acc[q][r], ss[q]);
 #pragma unroll
             for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = wn[ks];
             cc = cn;
         }
         const double ln = lognorm[s];
         // fold the four lane groups (rows of the C tiles) so that group g keeps frame tile g
-        const double keep_a = hi32 ? ss[2] : ss[0], send_a = hi32 ? ss[0] : ss[2];
-        const double keep_b = hi32 ? ss[3] : ss[1], send_b = hi32 ? ss[1] : ss[3];
-        const double v0 = keep_a + __shfl_xor(send_a, 32);
-        const double v1 = keep_b + __shfl_xor(send_b, 32);
-        const double keep = hi16 ? v1 : v0, send = hi16 ? v0 : v1;
-        const double maha = keep + __shfl_xor(send, 16);
+        em_swap32(ss[0], ss[2]);
+        em_swap32(ss[1], ss[3]);
+        double v0 = ss[0] + ss[2];            // lanes 0..31: frame tile 0, lanes 32..63: frame tile 2
+        double v1 = ss[1] + ss[3];            // frame tiles 1 and 3
+        em_swap16(v0, v1);
+        const double maha = v0 + v1;
         const double lp = -0.5 * (ln + maha);
         if (n_mix == 1) {
             tile[wave][lane][(s ^ lane) & 63] = (float)lp;
