@@ -241,6 +241,8 @@ extern "C" int lsr_ctx_create(int device, lsr_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return LSR_ERR_HIP;
     lsr_ctx* ctx = new lsr_ctx();
     ctx->device = device;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
     int rc = lsr_frontend_init(ctx);
     if (rc != LSR_OK) {
         fprintf(stderr, "lsr_ctx_create: %s\n", ctx->error.c_str());

@@ -20,6 +20,7 @@ struct lsr_buffer {
 
 struct lsr_ctx {
     int device = 0;
+    int n_cus = 256;                 // compute units of the device (sizes persistent grids)
     hipStream_t stream = nullptr;
     std::string error;
 
