@@ -261,44 +261,95 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 #define FN_FRAMES 64
 #define FN_HALO 8
 #define FN_STAGED (FN_FRAMES + 2 * FN_HALO)
+#define FN_MEL_STRIDE 44
+#define FN_DCT_GROUPS (256 / LSR_N_MFCC)
 
 __global__ __launch_bounds__(256) void lsr_mfcc_finish_kernel(
     const float* __restrict__ mel, const unsigned int* __restrict__ uttmax, const int64_t* __restrict__ frame_off,
     const int32_t* __restrict__ frame_utt, int64_t total_frames, const double* __restrict__ dct,
     float* __restrict__ feats) {
-    __shared__ float logmel[FN_STAGED][LSR_N_MELS + 1];
+    // rows of 44 floats: 16-byte aligned for 128-bit reads, and the rows a wavefront reads at once
+    // (five consecutive frames) start on different banks
+    __shared__ __attribute__((aligned(16))) float logmel[FN_STAGED][FN_MEL_STRIDE];
     __shared__ float ceps[FN_STAGED][LSR_N_MFCC];
     __shared__ float outb[FN_FRAMES][LSR_DIM];
-    __shared__ double dctm[LSR_N_MFCC * LSR_N_MELS];
+    __shared__ float refdb[FN_STAGED];
+    __shared__ int pos_t[FN_FRAMES], len_t[FN_FRAMES];     // frame's index in its utterance, utterance length
 
     const int tid = threadIdx.x;
     const int64_t g0 = (int64_t)blockIdx.x * FN_FRAMES;
-    for (int i = tid; i < LSR_N_MFCC * LSR_N_MELS; i += 256) dctm[i] = dct[i];
+
+    // Every global load of the block is issued before the first use, so the block pays one memory
+    // latency: the staged mel rows are one contiguous run of FN_STAGED * 40 floats (clamped at the
+    // ends of the batch), fetched as 128-bit loads.
+    constexpr int N_VEC = FN_STAGED * LSR_N_MELS / 4, VEC_PER_THREAD = (N_VEC + 255) / 256;
+    float4 mv[VEC_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < VEC_PER_THREAD; ++u) {
+        const int e = 4 * (tid + 256 * u);
+        int64_t g = g0 - FN_HALO + e / LSR_N_MELS;
+        g = g < 0 ? 0 : (g >= total_frames ? total_frames - 1 : g);
+        mv[u] = *(const float4*)(mel + g * LSR_N_MELS + e % LSR_N_MELS);
+    }
+    // thread (k, j) of the DCT below keeps row k of the DCT matrix in registers
+    const int dk = tid % LSR_N_MFCC, dj = tid / LSR_N_MFCC;
+    double drow[LSR_N_MELS];
+#pragma unroll
+    for (int n = 0; n < LSR_N_MELS; ++n) drow[n] = dct[dk * LSR_N_MELS + n];
 
     // power_to_db(ref=max, amin=1e-10, top_db=80): the utterance maximum maps to exactly 0 dB,
     // so the floor is the constant -80
-    for (int i = tid; i < FN_STAGED * LSR_N_MELS; i += 256) {
-        const int fr = i / LSR_N_MELS, band = i % LSR_N_MELS;
-        const int64_t g = g0 - FN_HALO + fr;
-        float v = 0.f;
+    if (tid < FN_STAGED) {
+        const int64_t g = g0 - FN_HALO + tid;
+        float r = 0.f;
         if (g >= 0 && g < total_frames) {
-            const float amin = 1e-10f;
-            const float ref = __uint_as_float(uttmax[frame_utt[g]]);
-            const float m = mel[g * LSR_N_MELS + band];
-            const float a = 10.0f * log10f(fmaxf(amin, m));
-            const float r = 10.0f * log10f(fmaxf(amin, ref));
-            v = fmaxf(a - r, -80.0f);
+            const int b = frame_utt[g];
+            r = 10.0f * log10f(fmaxf(1e-10f, __uint_as_float(uttmax[b])));
+            const int fo = tid - FN_HALO;
+            if (fo >= 0 && fo < FN_FRAMES) {
+                const int64_t lo = frame_off[b];
+                pos_t[fo] = (int)(g - lo);
+                len_t[fo] = (int)(frame_off[b + 1] - lo);
+            }
         }
-        logmel[fr][band] = v;
+        refdb[tid] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < VEC_PER_THREAD; ++u) {
+        const int e = 4 * (tid + 256 * u);
+        if (e < FN_STAGED * LSR_N_MELS) {
+            const int fr = e / LSR_N_MELS, band = e % LSR_N_MELS;
+            const int64_t g = g0 - FN_HALO + fr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g >= 0 && g < total_frames) {
+                const float r = refdb[fr];
+                v.x = fmaxf(10.0f * log10f(fmaxf(1e-10f, mv[u].x)) - r, -80.0f);
+                v.y = fmaxf(10.0f * log10f(fmaxf(1e-10f, mv[u].y)) - r, -80.0f);
+                v.z = fmaxf(10.0f * log10f(fmaxf(1e-10f, mv[u].z)) - r, -80.0f);
+                v.w = fmaxf(10.0f * log10f(fmaxf(1e-10f, mv[u].w)) - r, -80.0f);
+            }
+            *(float4*)&logmel[fr][band] = v;
+        }
     }
     __syncthreads();
 
-    for (int i = tid; i < FN_STAGED * LSR_N_MFCC; i += 256) {
-        const int fr = i / LSR_N_MFCC, k = i % LSR_N_MFCC;
-        double acc = 0.0;
-#pragma unroll 8
-        for (int n = 0; n < LSR_N_MELS; ++n) acc = fma(dctm[k * LSR_N_MELS + n], (double)logmel[fr][n], acc);
-        ceps[fr][k] = (float)acc;
+    // DCT-II: thread (k, j) produces coefficient k of frames j, j + 19, ...; the 13 threads of a
+    // frame read the same log-mel row (LDS broadcast)
+    if (dj < FN_DCT_GROUPS) {
+        for (int fr = dj; fr < FN_STAGED; fr += FN_DCT_GROUPS) {
+            const float4* row = (const float4*)logmel[fr];
+            double acc = 0.0;
+#pragma unroll
+            for (int n4 = 0; n4 < LSR_N_MELS / 4; ++n4) {
+                const float4 v = row[n4];
+                acc = fma(drow[4 * n4], (double)v.x, acc);
+                acc = fma(drow[4 * n4 + 1], (double)v.y, acc);
+                acc = fma(drow[4 * n4 + 2], (double)v.z, acc);
+                acc = fma(drow[4 * n4 + 3], (double)v.w, acc);
+            }
+            ceps[fr][dk] = (float)acc;
+        }
     }
     __syncthreads();
 
@@ -308,9 +359,7 @@ __global__ __launch_bounds__(256) void lsr_mfcc_finish_kernel(
         const int fo = i / LSR_N_MFCC, k = i % LSR_N_MFCC;
         const int64_t g = g0 + fo;
         if (g < total_frames) {
-            const int b = frame_utt[g];
-            const int64_t lo = frame_off[b];
-            const int t = (int)(g - lo), T = (int)(frame_off[b + 1] - lo);
+            const int t = pos_t[fo], T = len_t[fo];
             int tc = t < 4 ? 4 : t;
             if (tc > T - 5) tc = T - 5;
             const int c = fo + FN_HALO + (tc - t);
