@@ -54,10 +54,25 @@ __device__ __forceinline__ void dft4(const cplx a, const cplx b, const cplx c, c
     X[3] = cadd(s1, cmul_posi(s3));
 }
 
-__global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, int32_t* __restrict__ frame_utt) {
+// Per-frame record for the transform kernel, so that it reaches a frame's samples with one load
+// instead of a chain of three: x/y = position in the audio buffer of sample 0 of the centred
+// window (may lie before the clip), z = utterance, w = [lo, hi) range of window samples that fall
+// inside the clip (lo | hi << 16); the rest of the window is the zero padding.
+__global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, const int64_t* __restrict__ sample_off,
+                                       int32_t* __restrict__ frame_utt, int4* __restrict__ frame_info) {
     const int b = blockIdx.x;
     const int64_t lo = frame_off[b], hi = frame_off[b + 1];
-    for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) frame_utt[f] = b;
+    const int64_t s0 = sample_off[b], ns = sample_off[b + 1] - s0;
+    for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) {
+        frame_utt[f] = b;
+        const int64_t first = (int64_t)LSR_HOP * (f - lo) - LSR_N_FFT / 2;           // centre padding
+        const int64_t start = s0 + first;
+        int64_t vlo = first < 0 ? -first : 0, vhi = ns - first;
+        if (vlo > LSR_N_FFT) vlo = LSR_N_FFT;
+        if (vhi > LSR_N_FFT) vhi = LSR_N_FFT;
+        if (vhi < vlo) vhi = vlo;
+        frame_info[f] = make_int4((int)(uint32_t)start, (int)(start >> 32), b, (int)(vlo | (vhi << 16)));
+    }
 }
 
 #define MP_FRAMES 4          // frames per wavefront pass
@@ -66,35 +81,31 @@ __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, in
 #define MP_PLD 164
 #define MP_SLOT_BINS 6       // bins per mel slot (61 slots cover the 260 non-zero weights)
 
-// samples 2m, 2m+1 (m = 16 n1 + n2, n1 = 0..9) of frame `g` for one lane; zero outside the clip
+__device__ __forceinline__ int4 mp_load_info(const int4* __restrict__ frame_info, int64_t total_frames, int64_t g) {
+    return g < total_frames ? frame_info[g] : make_int4(0, 0, 0, 0);      // empty range: all padding
+}
+
+// samples 2m, 2m+1 (m = 16 n1 + n2, n1 = 0..9) of the frame described by `info` for one lane; zero
+// outside the clip
 template <typename SAMPLE>
-__device__ __forceinline__ void mp_load_samples(const SAMPLE* __restrict__ audio, const int64_t* __restrict__ sample_off,
-                                                const int64_t* __restrict__ frame_off,
-                                                const int32_t* __restrict__ frame_utt, int64_t total_frames, int64_t g,
-                                                int n2, float (&xs)[20]) {
-    if (g < total_frames) {
-        const int b = frame_utt[g];
-        const int64_t s0 = sample_off[b];
-        const int64_t ns = sample_off[b + 1] - s0;
-        const int64_t first = (int64_t)LSR_HOP * (g - frame_off[b]) - LSR_N_FFT / 2;   // centre padding
-        const SAMPLE* sig = audio + s0 + first + 2 * n2;
-        if (first >= 0 && first + LSR_N_FFT <= ns) {
+__device__ __forceinline__ void mp_load_samples(const SAMPLE* __restrict__ audio, const int4 info, int n2,
+                                                float (&xs)[20]) {
+    const int lo = info.w & 0xffff, hi = (int)((unsigned)info.w >> 16);
+    const int64_t start = (int64_t)(((uint64_t)(uint32_t)info.y << 32) | (uint32_t)info.x);
+    const SAMPLE* sig = audio + start + 2 * n2;
+    if (lo == 0 && hi == LSR_N_FFT) {
 #pragma unroll
-            for (int n1 = 0; n1 < 10; ++n1) {
-                xs[2 * n1] = (float)sig[32 * n1];
-                xs[2 * n1 + 1] = (float)sig[32 * n1 + 1];
-            }
-        } else {
-#pragma unroll
-            for (int n1 = 0; n1 < 10; ++n1) {
-                const int64_t i0 = first + 2 * n2 + 32 * n1, i1 = i0 + 1;
-                xs[2 * n1] = (i0 >= 0 && i0 < ns) ? (float)sig[32 * n1] : 0.f;
-                xs[2 * n1 + 1] = (i1 >= 0 && i1 < ns) ? (float)sig[32 * n1 + 1] : 0.f;
-            }
+        for (int n1 = 0; n1 < 10; ++n1) {
+            xs[2 * n1] = (float)sig[32 * n1];
+            xs[2 * n1 + 1] = (float)sig[32 * n1 + 1];
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 20; ++i) xs[i] = 0.f;
+        for (int n1 = 0; n1 < 10; ++n1) {
+            const int i0 = 2 * n2 + 32 * n1, i1 = i0 + 1;
+            xs[2 * n1] = (i0 >= lo && i0 < hi) ? (float)sig[32 * n1] : 0.f;
+            xs[2 * n1 + 1] = (i1 >= lo && i1 < hi) ? (float)sig[32 * n1 + 1] : 0.f;
+        }
     }
 }
 
@@ -121,8 +132,8 @@ __device__ __forceinline__ void mp_untangle(const cplx* __restrict__ z, float* _
 
 template <typename SAMPLE>
 __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
-    const SAMPLE* __restrict__ audio, const int64_t* __restrict__ sample_off, const int64_t* __restrict__ frame_off,
-    const int32_t* __restrict__ frame_utt, int64_t total_frames, int64_t n_groups, const double* __restrict__ window,
+    const SAMPLE* __restrict__ audio, const int4* __restrict__ frame_info, int64_t total_frames, int64_t n_groups,
+    const double* __restrict__ window,
     const double* __restrict__ tw160, const double* __restrict__ tw320, const float* __restrict__ slot_w,
     const int* __restrict__ slot_info, const int* __restrict__ band_slots, float* __restrict__ mel,
     unsigned int* __restrict__ uttmax) {
@@ -151,13 +162,18 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 #pragma unroll
     for (int j = 0; j < MP_SLOT_BINS; ++j) sw[j] = slot_w[lane * MP_SLOT_BINS + j];
     const int slot_start = slot_info[lane];
+    // software pipeline over the grid-stride loop: samples one group ahead, frame records two ahead,
+    // so no load is waited for in the iteration that issues it
     float xs[20];
-    mp_load_samples(audio, sample_off, frame_off, frame_utt, total_frames, (int64_t)blockIdx.x * MP_FRAMES + f, n2, xs);
+    int4 info_cur = mp_load_info(frame_info, total_frames, (int64_t)blockIdx.x * MP_FRAMES + f);
+    int4 info_nxt = mp_load_info(frame_info, total_frames, ((int64_t)blockIdx.x + gridDim.x) * MP_FRAMES + f);
+    mp_load_samples(audio, info_cur, n2, xs);
     __syncthreads();
 
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t g0 = grp * MP_FRAMES;
         if (lane < MP_FRAMES) fmax_bits[lane] = 0u;
+        const int utt_cur = info_cur.z;
 
         // ---- stage A: 10-point DFTs over n1 for fixed (frame, n2) ------------------------------
         {
@@ -168,8 +184,9 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
                 z[n1] = {w.re * (double)xs[2 * n1], w.im * (double)xs[2 * n1 + 1]};
             }
             // the next group's samples travel while this group is transformed
-            mp_load_samples(audio, sample_off, frame_off, frame_utt, total_frames,
-                            (grp + gridDim.x) * MP_FRAMES + f, n2, xs);
+            mp_load_samples(audio, info_nxt, n2, xs);
+            info_cur = info_nxt;
+            info_nxt = mp_load_info(frame_info, total_frames, (grp + 2 * (int64_t)gridDim.x) * MP_FRAMES + f);
             cplx E[5], O[5];
             dft5(z[0], z[2], z[4], z[6], z[8], E);
             dft5(z[1], z[3], z[5], z[7], z[9], O);
@@ -254,7 +271,8 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
             }
         }
         __syncthreads();
-        if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[frame_utt[g0 + lane]], fmax_bits[lane]);
+        const int utt = __shfl(utt_cur, (lane & 3) * 16);          // lane l < 4 reports frame l of the group
+        if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[utt], fmax_bits[lane]);
     }
 }
 
@@ -408,13 +426,16 @@ int lsr_launch_mfcc(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const i
     if ((rc = lsr_reserve(ctx, &ctx->ws_frame_utt, (size_t)total_frames * sizeof(int32_t), "frame index"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_mel, (size_t)total_frames * LSR_N_MELS * sizeof(float), "mel energies"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_uttmax, (size_t)n_utts * sizeof(unsigned int), "utterance maxima"))) return rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_frame_info, (size_t)total_frames * sizeof(int4), "frame records"))) return rc;
+    int4* frame_info = (int4*)ctx->ws_frame_info.ptr;
     int32_t* frame_utt = (int32_t*)ctx->ws_frame_utt.ptr;
     float* mel = (float*)ctx->ws_mel.ptr;
     unsigned int* uttmax = (unsigned int*)ctx->ws_uttmax.ptr;
     LSR_HIP_CHECK(ctx, hipMemsetAsync(uttmax, 0, (size_t)n_utts * sizeof(unsigned int), ctx->stream));
 
     lsr_prof_begin(ctx, LSR_K_FRAME_INDEX);
-    hipLaunchKernelGGL(lsr_frame_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, frame_off_d, frame_utt);
+    hipLaunchKernelGGL(lsr_frame_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, frame_off_d, sample_off_d,
+                       frame_utt, frame_info);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_frame_index_kernel");
 
@@ -425,12 +446,12 @@ int lsr_launch_mfcc(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const i
     lsr_prof_begin(ctx, LSR_K_MEL_POWER);
     if (audio_is_i16)
         hipLaunchKernelGGL(lsr_mel_power_kernel<int16_t>, dim3(blocks_mp), dim3(64), 0, ctx->stream,
-                           (const int16_t*)audio_d, sample_off_d, frame_off_d, frame_utt, total_frames, n_groups,
+                           (const int16_t*)audio_d, frame_info, total_frames, n_groups,
                            ctx->d_window, ctx->d_tw160, ctx->d_tw320, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots,
                            mel, uttmax);
     else
         hipLaunchKernelGGL(lsr_mel_power_kernel<float>, dim3(blocks_mp), dim3(64), 0, ctx->stream,
-                           (const float*)audio_d, sample_off_d, frame_off_d, frame_utt, total_frames, n_groups,
+                           (const float*)audio_d, frame_info, total_frames, n_groups,
                            ctx->d_window, ctx->d_tw160, ctx->d_tw320, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots,
                            mel, uttmax);
     lsr_prof_end(ctx);
