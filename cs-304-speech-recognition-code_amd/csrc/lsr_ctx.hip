@@ -269,7 +269,7 @@ extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
     free_ptr(ctx->d_lower_of);
     free_ptr(ctx->d_upper_of);
     lsr_buffer* bufs[] = {&ctx->ws_frame_utt, &ctx->ws_mel, &ctx->ws_uttmax, &ctx->ws_feats,
-                          &ctx->ws_ll, &ctx->ws_tracer, &ctx->ws_slab, &ctx->ws_sep, &ctx->ws_frame_info};
+                          &ctx->ws_ll, &ctx->ws_tracer, &ctx->ws_slab, &ctx->ws_sep, &ctx->ws_frame_info, &ctx->ws_sort};
     for (lsr_buffer* b : bufs) free_ptr(b->ptr);
     for (auto& p : ctx->pend) {
         (void)hipEventDestroy(p.start);

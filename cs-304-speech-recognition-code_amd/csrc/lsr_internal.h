@@ -53,7 +53,7 @@ struct lsr_ctx {
     int between_is_f64 = 1;
 
     // workspace
-    lsr_buffer ws_frame_utt, ws_mel, ws_uttmax, ws_feats, ws_ll, ws_tracer, ws_slab, ws_sep, ws_frame_info;
+    lsr_buffer ws_frame_utt, ws_mel, ws_uttmax, ws_feats, ws_ll, ws_tracer, ws_slab, ws_sep, ws_frame_info, ws_sort;
 
     // profiling
     bool profiling = false;

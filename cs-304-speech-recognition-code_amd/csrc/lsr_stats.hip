@@ -1,118 +1,228 @@
 // Sufficient statistics of a hard alignment: for every slot (model state) the frame count,
 // the sum of the frames and the sum of their outer products, all in float64.
 //
-// Frames arrive in utterance order, so a slot persists over runs of consecutive frames.  Each
-// workgroup owns a contiguous range of frames; its 256 threads each own up to seven entries of
-// the 40 x 40 outer product of the augmented frame [x, 1] (which holds sum_xx, sum_x and the
-// count at once), accumulate them in registers while the slot stays the same and add them to
-// the workgroup's private slab in global memory when it changes.  A second kernel adds the
-// slabs in workgroup order, so the result does not depend on scheduling.
+// The sums of one slot are the Gram matrix X^T X of its frames augmented with a constant 1
+// ([x, 1]: 40 columns, holding sum_xx, sum_x and the count at once), which is matrix-unit work:
+//   1. a stable counting sort of the frame indices by slot (per-wavefront histograms of 1024-frame
+//      units, a scan over units, a scatter that ranks equal slots inside a wavefront by lane),
+//   2. one wavefront per (slot, part of the slot's sorted list): v_mfma_f64_16x16x4_f64 with four
+//      frames per k-step; lane (g, c) loads features c, 16 + c, 32 + c of frame 4 ks + g, and the same
+//      register is the A operand (X^T) of its row tile and the B operand (X) of its column tile, so
+//      a k-step is 3 gathers and 6 MFMAs (upper triangle of the 3 x 3 tiles),
+//   3. a reduction that adds the parts of a slot in part order and unpacks the tiles.
+// Every step has a fixed order of additions, so the result does not depend on scheduling.
 #include "lsr_internal.h"
 
-#define ST_AUG 40
-#define ST_ENTRIES (ST_AUG * ST_AUG)
-#define ST_PER_THREAD 7
-#define ST_CHUNK 64
-#define ST_MAX_BLOCKS 256
+typedef double v4d __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void lsr_stats_accumulate_kernel(const float* __restrict__ feats,
-                                                                   const int32_t* __restrict__ slot,
-                                                                   int64_t total_frames, int64_t frames_per_block,
-                                                                   int n_slots, double* __restrict__ slabs) {
-    __shared__ float xs[ST_CHUNK][ST_AUG];
-    __shared__ int sl[ST_CHUNK];
-    const int tid = threadIdx.x;
-    double* slab = slabs + (size_t)blockIdx.x * n_slots * ST_ENTRIES;
-    int ei[ST_PER_THREAD], ej[ST_PER_THREAD];
-    double acc[ST_PER_THREAD];
-#pragma unroll
-    for (int r = 0; r < ST_PER_THREAD; ++r) {
-        const int e = tid + 256 * r;
-        ei[r] = e < ST_ENTRIES ? e / ST_AUG : 0;
-        ej[r] = e < ST_ENTRIES ? e % ST_AUG : 0;
-        acc[r] = 0.0;
+#define SS_UNIT 1024         // frames per wavefront in the sort kernels
+#define SS_TILES 6           // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+#define SS_AUG 40            // 39 features + the constant
+
+__global__ __launch_bounds__(64) void lsr_slot_count_kernel(const int32_t* __restrict__ slot, int64_t total_frames,
+                                                            int n_slots, int32_t* __restrict__ counts) {
+    extern __shared__ int cnt[];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n_slots; i += 64) cnt[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SS_UNIT;
+    for (int it = 0; it < SS_UNIT / 64; ++it) {
+        const int64_t f = base + it * 64 + lane;
+        const int s = f < total_frames ? slot[f] : -1;
+        if (s >= 0 && s < n_slots) atomicAdd(&cnt[s], 1);
     }
-    const int64_t lo = (int64_t)blockIdx.x * frames_per_block;
-    int64_t hi = lo + frames_per_block;
-    if (hi > total_frames) hi = total_frames;
-    int cur = -1;
-    for (int64_t c0 = lo; c0 < hi; c0 += ST_CHUNK) {
-        const int nf = (int)((hi - c0 < ST_CHUNK) ? hi - c0 : ST_CHUNK);
+    __syncthreads();
+    for (int i = lane; i < n_slots; i += 64) counts[(size_t)i * gridDim.x + blockIdx.x] = cnt[i];      // [slot][unit]
+}
+
+// exclusive scan of `n` ints in place with one 256-thread workgroup (contiguous chunk per thread);
+// returns the total in every thread
+__device__ int ss_block_scan(int32_t* __restrict__ v, int n) {
+    __shared__ int part[256];
+    const int t = threadIdx.x;
+    const int chunk = (n + 255) / 256, lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += v[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                  // inclusive Hillis-Steele scan of the chunk sums
+        const int add = t >= d ? part[t - d] : 0;
         __syncthreads();
-        for (int i = tid; i < nf * LSR_DIM; i += 256) xs[i / LSR_DIM][i % LSR_DIM] = feats[c0 * LSR_DIM + i];
-        if (tid < nf) {
-            xs[tid][LSR_DIM] = 1.0f;
-            const int s = slot[c0 + tid];
-            sl[tid] = (s >= 0 && s < n_slots) ? s : -1;
-        }
+        part[t] += add;
         __syncthreads();
-        for (int f = 0; f < nf; ++f) {
-            const int s = sl[f];
-            if (s != cur) {
-                if (cur >= 0) {
-#pragma unroll
-                    for (int r = 0; r < ST_PER_THREAD; ++r) {
-                        const int e = tid + 256 * r;
-                        if (e < ST_ENTRIES) slab[(size_t)cur * ST_ENTRIES + e] += acc[r];
-                        acc[r] = 0.0;
-                    }
-                }
-                cur = s;
-            }
-            if (s >= 0) {
-#pragma unroll
-                for (int r = 0; r < ST_PER_THREAD; ++r)
-                    acc[r] = fma((double)xs[f][ei[r]], (double)xs[f][ej[r]], acc[r]);
-            }
-        }
     }
-    if (cur >= 0) {
-#pragma unroll
-        for (int r = 0; r < ST_PER_THREAD; ++r) {
-            const int e = tid + 256 * r;
-            if (e < ST_ENTRIES) slab[(size_t)cur * ST_ENTRIES + e] += acc[r];
+    int run = part[t] - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int c = v[i];
+        v[i] = run;
+        run += c;
+    }
+    const int total = part[255];
+    __syncthreads();
+    return total;
+}
+
+// counts[slot][unit] -> position, relative to the slot's segment, of the unit's first frame of
+// that slot in the sorted list (one workgroup per slot); slot_n[slot] = length of the segment
+__global__ __launch_bounds__(256) void lsr_slot_scan_kernel(int32_t* __restrict__ counts, int n_units,
+                                                            int32_t* __restrict__ slot_n) {
+    const int total = ss_block_scan(counts + (size_t)blockIdx.x * n_units, n_units);
+    if (threadIdx.x == 0) slot_n[blockIdx.x] = total;
+}
+
+// slot_base[slot] = start of the slot's segment
+__global__ __launch_bounds__(256) void lsr_slot_base_kernel(const int32_t* __restrict__ slot_n, int n_slots,
+                                                            int32_t* __restrict__ slot_base) {
+    for (int i = threadIdx.x; i < n_slots; i += 256) slot_base[i] = slot_n[i];
+    __syncthreads();
+    ss_block_scan(slot_base, n_slots);
+}
+
+__global__ __launch_bounds__(64) void lsr_slot_scatter_kernel(const int32_t* __restrict__ slot, int64_t total_frames,
+                                                              int n_slots, const int32_t* __restrict__ offsets,
+                                                              const int32_t* __restrict__ slot_base,
+                                                              int32_t* __restrict__ order) {
+    extern __shared__ int cnt[];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n_slots; i += 64) cnt[i] = slot_base[i] + offsets[(size_t)i * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SS_UNIT;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int it = 0; it < SS_UNIT / 64; ++it) {
+        const int64_t f = base + it * 64 + lane;
+        int s = f < total_frames ? slot[f] : -1;
+        if (s >= n_slots) s = -1;
+        bool todo = s >= 0;
+        // frames of equal slot keep their order: rank by lane inside the wavefront
+        while (true) {
+            const unsigned long long pending = __ballot(todo);
+            if (pending == 0ull) break;
+            const int lead = __shfl(s, __ffsll((long long)pending) - 1);
+            const unsigned long long same = __ballot(todo && s == lead);
+            const int start = cnt[lead];
+            __syncthreads();                                     // every lane has read the counter
+            if (todo && s == lead) {
+                order[start + __popcll(same & below)] = (int32_t)f;
+                todo = false;
+            }
+            if (lane == 0) cnt[lead] = start + __popcll(same);
+            __syncthreads();
         }
     }
 }
 
-__global__ __launch_bounds__(256) void lsr_stats_reduce_kernel(const double* __restrict__ slabs, int n_blocks,
-                                                               int n_slots, double* __restrict__ count,
-                                                               double* __restrict__ sum_x,
-                                                               double* __restrict__ sum_xx) {
+__device__ __forceinline__ void ss_load(const float* __restrict__ feats, const int32_t* __restrict__ order, int pos,
+                                        int end, int c, double (&x)[3]) {
+    x[0] = x[1] = x[2] = 0.0;
+    if (pos < end) {
+        const float* row = feats + (size_t)order[pos] * LSR_DIM;
+        x[0] = (double)row[c];
+        x[1] = (double)row[16 + c];
+        x[2] = c < 7 ? (double)row[32 + c] : (c == 7 ? 1.0 : 0.0);       // column 39 is the constant
+    }
+}
+
+__global__ __launch_bounds__(64) void lsr_gram_kernel(const float* __restrict__ feats, const int32_t* __restrict__ order,
+                                                      const int32_t* __restrict__ slot_base,
+                                                      const int32_t* __restrict__ slot_n, int n_parts,
+                                                      v4d* __restrict__ partial) {
+    const int s = blockIdx.x / n_parts, part = blockIdx.x % n_parts;
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int n = slot_n[s], base = slot_base[s];
+    const int n_ks = (n + 3) / 4;
+    const int ks0 = (int)((int64_t)part * n_ks / n_parts), ks1 = (int)((int64_t)(part + 1) * n_ks / n_parts);
+    const int end = base + n;
+    v4d acc[SS_TILES];
+#pragma unroll
+    for (int t = 0; t < SS_TILES; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int ks = ks0; ks < ks1; ks += 4) {
+        double x[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = ks + u;
+            ss_load(feats, order, k < ks1 ? base + 4 * k + g : end, end, c, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][0], x[u][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][0], x[u][1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][0], x[u][2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][1], x[u][1], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][1], x[u][2], acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][2], x[u][2], acc[5], 0, 0, 0);
+        }
+    }
+    v4d* out = partial + ((size_t)blockIdx.x * SS_TILES) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < SS_TILES; ++t) out[t * 64] = acc[t];
+}
+
+// entry (i, j), i <= j, of the augmented Gram matrix lives in tile (i / 16, j / 16) at lane
+// (i % 4) * 16 + j % 16, register (i % 16) / 4
+__global__ __launch_bounds__(256) void lsr_gram_reduce_kernel(const double* __restrict__ partial, int n_parts,
+                                                              double* __restrict__ count, double* __restrict__ sum_x,
+                                                              double* __restrict__ sum_xx) {
     const int s = blockIdx.x;
-    for (int e = threadIdx.x; e < ST_ENTRIES; e += 256) {
+    for (int e = threadIdx.x; e < SS_AUG * SS_AUG; e += 256) {
+        int i = e / SS_AUG, j = e % SS_AUG;
+        const int row = i, colm = j;
+        if (i > j) {
+            const int t = i;
+            i = j;
+            j = t;
+        }
+        const int ti = i / 16, tj = j / 16;
+        const int tile = ti == 0 ? tj : (ti == 1 ? 2 + tj : 5);
+        const int lane = (i % 4) * 16 + j % 16, reg = (i % 16) / 4;
         double t = 0.0;
-        for (int b = 0; b < n_blocks; ++b) t += slabs[((size_t)b * n_slots + s) * ST_ENTRIES + e];
-        const int i = e / ST_AUG, j = e % ST_AUG;
-        if (i < LSR_DIM && j < LSR_DIM)
-            sum_xx[((size_t)s * LSR_DIM + i) * LSR_DIM + j] = t;
-        else if (i == LSR_DIM && j < LSR_DIM)
-            sum_x[(size_t)s * LSR_DIM + j] = t;
-        else if (i == LSR_DIM && j == LSR_DIM)
+        for (int p = 0; p < n_parts; ++p)
+            t += partial[((((size_t)s * n_parts + p) * SS_TILES + tile) * 64 + lane) * 4 + reg];
+        if (row < LSR_DIM && colm < LSR_DIM)
+            sum_xx[((size_t)s * LSR_DIM + row) * LSR_DIM + colm] = t;
+        else if (row == LSR_DIM && colm < LSR_DIM)
+            sum_x[(size_t)s * LSR_DIM + colm] = t;
+        else if (row == LSR_DIM && colm == LSR_DIM)
             count[s] = t;
     }
 }
 
 int lsr_launch_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, int64_t total_frames, int n_slots,
                      double* count_d, double* sum_x_d, double* sum_xx_d) {
-    int64_t blocks = (total_frames + 1023) / 1024;
-    if (blocks > ST_MAX_BLOCKS) blocks = ST_MAX_BLOCKS;
-    if (blocks < 1) blocks = 1;
-    int64_t per_block = (total_frames + blocks - 1) / blocks;
-    per_block = (per_block + ST_CHUNK - 1) / ST_CHUNK * ST_CHUNK;
-    const size_t slab_bytes = (size_t)blocks * n_slots * ST_ENTRIES * sizeof(double);
-    int rc = lsr_reserve(ctx, &ctx->ws_slab, slab_bytes, "statistics slabs");
+    const int n_units = (int)((total_frames + SS_UNIT - 1) / SS_UNIT);
+    int n_parts = 4096 / n_slots;
+    if (n_parts < 1) n_parts = 1;
+    if (n_parts > 256) n_parts = 256;
+    // sort workspace: counts/offsets [slots][units], slot_base, slot_n, order [frames]
+    const size_t n_counts = (size_t)n_units * n_slots;
+    const size_t sort_ints = n_counts + 2 * (size_t)n_slots + (size_t)total_frames;
+    int rc = lsr_reserve(ctx, &ctx->ws_sort, sort_ints * sizeof(int32_t), "slot sort");
     if (rc) return rc;
-    double* slabs = (double*)ctx->ws_slab.ptr;
-    LSR_HIP_CHECK(ctx, hipMemsetAsync(slabs, 0, slab_bytes, ctx->stream));
+    const size_t partial_bytes = (size_t)n_slots * n_parts * SS_TILES * 64 * sizeof(v4d);
+    if ((rc = lsr_reserve(ctx, &ctx->ws_slab, partial_bytes, "statistics partial sums"))) return rc;
+    int32_t* counts = (int32_t*)ctx->ws_sort.ptr;
+    int32_t* slot_base = counts + n_counts;
+    int32_t* slot_n = slot_base + n_slots;
+    int32_t* order = slot_n + n_slots;
+    v4d* partial = (v4d*)ctx->ws_slab.ptr;
+    const size_t lds = (size_t)n_slots * sizeof(int);
     lsr_prof_begin(ctx, LSR_K_STATS);
-    hipLaunchKernelGGL(lsr_stats_accumulate_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, feats_d, slot_d,
-                       total_frames, per_block, n_slots, slabs);
-    LSR_LAUNCH_CHECK(ctx, "lsr_stats_accumulate_kernel");
-    hipLaunchKernelGGL(lsr_stats_reduce_kernel, dim3((unsigned)n_slots), dim3(256), 0, ctx->stream, slabs, (int)blocks,
-                       n_slots, count_d, sum_x_d, sum_xx_d);
+    hipLaunchKernelGGL(lsr_slot_count_kernel, dim3(n_units), dim3(64), lds, ctx->stream, slot_d, total_frames, n_slots,
+                       counts);
+    LSR_LAUNCH_CHECK(ctx, "lsr_slot_count_kernel");
+    hipLaunchKernelGGL(lsr_slot_scan_kernel, dim3(n_slots), dim3(256), 0, ctx->stream, counts, n_units, slot_n);
+    LSR_LAUNCH_CHECK(ctx, "lsr_slot_scan_kernel");
+    hipLaunchKernelGGL(lsr_slot_base_kernel, dim3(1), dim3(256), 0, ctx->stream, slot_n, n_slots, slot_base);
+    LSR_LAUNCH_CHECK(ctx, "lsr_slot_base_kernel");
+    hipLaunchKernelGGL(lsr_slot_scatter_kernel, dim3(n_units), dim3(64), lds, ctx->stream, slot_d, total_frames, n_slots,
+                       counts, slot_base, order);
+    LSR_LAUNCH_CHECK(ctx, "lsr_slot_scatter_kernel");
+    hipLaunchKernelGGL(lsr_gram_kernel, dim3((unsigned)(n_slots * n_parts)), dim3(64), 0, ctx->stream, feats_d, order,
+                       slot_base, slot_n, n_parts, partial);
+    LSR_LAUNCH_CHECK(ctx, "lsr_gram_kernel");
+    hipLaunchKernelGGL(lsr_gram_reduce_kernel, dim3((unsigned)n_slots), dim3(256), 0, ctx->stream,
+                       (const double*)partial, n_parts, count_d, sum_x_d, sum_xx_d);
     lsr_prof_end(ctx);
-    LSR_LAUNCH_CHECK(ctx, "lsr_stats_reduce_kernel");
+    LSR_LAUNCH_CHECK(ctx, "lsr_gram_reduce_kernel");
     return LSR_OK;
 }
 
