@@ -308,15 +308,18 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     for (int s = 0; s < n_states; ++s) {
         // c[j] = sum_k mean[k] U[k][j] (extended precision, rounded once); lane l, register r of the
         // C tile of row tile a holds row 16a + (l >> 4) + 4r
+        double c[LSR_DIM];
+        for (int j = 0; j < D; ++j) {
+            long double acc = 0.0L;
+            for (int k = 0; k < D; ++k)
+                acc += (long double)mean[(size_t)s * D + k] * (long double)whiten[((size_t)s * D + k) * D + j];
+            c[j] = -(double)acc;
+        }
         for (int a = 0; a < LSR_JTILES; ++a)
             for (int lane = 0; lane < 64; ++lane)
                 for (int r = 0; r < 4; ++r) {
                     const int j = 16 * a + (lane >> 4) + 4 * r;
-                    if (j >= D) continue;
-                    long double acc = 0.0L;
-                    for (int k = 0; k < D; ++k)
-                        acc += (long double)mean[(size_t)s * D + k] * (long double)whiten[((size_t)s * D + k) * D + j];
-                    cinit[(((size_t)s * LSR_JTILES + a) * 64 + lane) * 4 + r] = -(double)acc;
+                    if (j < D) cinit[(((size_t)s * LSR_JTILES + a) * 64 + lane) * 4 + r] = c[j];
                 }
         for (int k = 0; k < D; ++k)
             for (int j = k + 1; j < D; ++j)

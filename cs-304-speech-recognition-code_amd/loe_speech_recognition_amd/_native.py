@@ -257,7 +257,7 @@ class Engine:
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         whiten = np.ascontiguousarray(whiten, dtype=np.float64)
         if triangular:
-            whiten = np.stack([np.tril(np.linalg.qr(u.T)[1].T) for u in whiten])
+            whiten = np.tril(np.swapaxes(np.linalg.qr(np.swapaxes(whiten, 1, 2), mode="r"), 1, 2))      # batched
         log_norm = np.ascontiguousarray(log_norm, dtype=np.float64)
         S = mean.shape[0]
         assert mean.shape == (S, DIM) and whiten.shape == (S, DIM, DIM) and log_norm.shape == (S,)
