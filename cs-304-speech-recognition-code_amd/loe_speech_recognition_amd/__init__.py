@@ -12,11 +12,11 @@ from .hidden_markov_model import (MultivariateNormal, GaussianMixture, HiddenMar
                                   HiddenMarkovModelInference, HiddenMarkovModelMultiWord,
                                   HiddenMarkovModelTrainContinuous)
 from .model_collection import ModelCollection
-from .ti_digits import TI_DIGITS_LABELS
+from .ti_digits import TIDigits, DataLoader, TI_DIGITS_LABELS, TI_DIGITS_LABEL_TYPE
 from .signal_separation import SignalSeparation
 from . import _native, distributed, synthetic
 
 __all__ = ["MFCC", "SparseMatrix", "TransitionProbabilities", "LogTransitionProbabilities", "ModelBoundary", "Signal",
            "SortedSignals", "MultivariateNormal", "GaussianMixture", "HiddenMarkovModel", "HiddenMarkovModelTrainable",
            "HiddenMarkovModelInference", "HiddenMarkovModelMultiWord", "HiddenMarkovModelTrainContinuous",
-           "ModelCollection", "TI_DIGITS_LABELS", "SignalSeparation"]
+           "ModelCollection", "TI_DIGITS_LABELS", "TI_DIGITS_LABEL_TYPE", "TIDigits", "DataLoader", "SignalSeparation"]
