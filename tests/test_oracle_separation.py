@@ -64,3 +64,38 @@ def test_scan_status_codes():
     e = np.array([1] + [900] * 12 + [1, np.nan], np.float32)
     first, end, status, noise = so.scan(e, 10000.0, hi, lo, 2)
     assert (first, end, status) == (1, 14, so.OK) and noise.tolist() == [1] + [0] * 13 + [1]
+
+
+def test_host_bookkeeping_without_gpu():
+    """The host half of the product class (slicing, noise filing with carry-over, failures) fed with scan
+    results computed by the restatement instead of the device: must reproduce the reference's outputs."""
+    from loe_speech_recognition_amd import SignalSeparation
+
+    g = load("sep_g1.npz")
+    clips = fixture_clips(g)
+    sep = SignalSeparation(speech_high_threshold=0.06, speech_low_threshold=0.01)
+    fs = sep.frame_size
+
+    def fake_scan(signals):
+        first, end, status, noise, vol, off = [], [], [], [], [], [0]
+        for s in signals:
+            e = so.frame_energies(s, fs)
+            f, t, st, nz = so.scan(e, float(np.max(np.abs(s))), 0.06, 0.01, sep.maximum_silence_frames)
+            first.append(f); end.append(t); status.append(st); noise.append(nz); vol.append(np.max(np.abs(s)))
+            off.append(off[-1] + e.shape[0])
+        return {"first": np.array(first), "end": np.array(end), "status": np.array(status),
+                "noise": np.concatenate(noise), "max_volume": np.array(vol, np.float32), "scan_off": np.array(off)}
+
+    sep._scan = fake_scan
+    kept = sep.remove_empty_batch(clips)
+    ok = g["script_ok"].astype(bool)
+    assert len(kept) == int(ok.sum())
+    for arr, i in zip(kept, np.nonzero(ok)[0]):
+        assert np.array_equal(arr, clips[i][int(g["script_first"][i]) * fs:int(g["script_end"][i]) * fs])
+    noff, flat = g["script_noise_off"], g["script_noise"].astype(np.float32)
+    assert len(sep.get_all_noises()) == noff.shape[0] - 1
+    for k, nz in enumerate(sep.get_all_noises()):
+        assert np.array_equal(nz, flat[noff[k]:noff[k + 1]])
+    with pytest.raises(SignalSeparation.FailToProcess):
+        sep.remove_empty(clips[6])
+    assert sep.detect_speech(np.full(160, 5000.0, np.float32), "high") in (True, False)
