@@ -230,15 +230,18 @@ def main():
     label_cap = 16
     out = (eng.empty((ab.n,), torch.float32), None, eng.empty((ab.n, label_cap), torch.uint8),
            eng.empty((ab.n,), torch.int32))
-    gathered = torch.empty((world * ab.n, label_cap), dtype=torch.uint8, device=eng.device) if world > 1 else None
-
-    if world > 1 and backend != "nccl":                # gloo rehearsal: records travel through host memory
-        gathered = torch.empty((world * ab.n, label_cap), dtype=torch.uint8)
+    from loe_speech_recognition_amd.distributed import gather_label_records
+    state = {}
 
     def step():
         eng.recognize(ab, want_paths=False, label_cap=label_cap, out=out)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out[2] if backend == "nccl" else out[2].cpu())
+            # the exchange step of the path: every rank ends up with the label records (word ids + count)
+            # of the whole job, one all-gather of 20-byte records per step
+            if backend == "nccl":
+                state["records"] = gather_label_records(out[2], out[3], world * ab.n)
+            else:                                    # gloo rehearsal: records travel through host memory
+                state["records"] = gather_label_records(out[2].cpu(), out[3].cpu(), world * ab.n)
 
     def barrier():
         if world > 1:
@@ -266,7 +269,16 @@ def main():
     lab = out[2].cpu().numpy()
     cnt = out[3].cpu().numpy()
     strings = ["".join(names[w] for w in lab[i, :min(int(cnt[i]), label_cap)]) for i in range(ab.n)]
-    acc_truth = float(np.mean([a == b for a, b in zip(strings, truth)]))
+    n_right = sum(a == b for a, b in zip(strings, truth))
+    if world > 1:
+        t = torch.tensor([n_right], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n_right = float(t.item())
+        g_lab, g_cnt = state["records"]
+        assert g_lab.shape[0] == world * ab.n and g_cnt.shape[0] == world * ab.n
+        lo = rank * ab.n                             # this rank's slice of the gathered records is its own output
+        assert torch.equal(g_lab[lo:lo + ab.n].cpu()[:, :1], out[2].cpu()[:, :1]) and torch.equal(g_cnt[lo:lo + ab.n].cpu(), out[3].cpu())
+    acc_truth = float(n_right) / (world * ab.n)
 
     if rank == 0:
         kernels = {}
