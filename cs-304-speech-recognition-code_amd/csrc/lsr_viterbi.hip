@@ -91,6 +91,72 @@ __device__ __forceinline__ T wave_max(T v) {
     return lane63(v);
 }
 
+// float32 form with the lane move folded into the maximum (v_max_f32 with a DPP source; a lane
+// without a source is left as it is, which is what a running maximum needs).  The s_nop covers the
+// two wait states between a vector write and a DPP read of the same register.  Scores are never
+// NaN, so the hardware maximum needs no canonicalisation.
+template <>
+__device__ __forceinline__ float wave_max<float>(float v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return lane63(v);
+}
+
+// One step of the recursion for every lane: returns the new score, stores the back-pointer.
+template <int MODE>
+__device__ __forceinline__ float vit_step(const vit_args& A, float prev, float e, float a0, float a1, float a2,
+                                          bool is_entry, bool is_exit, int lane, int8_t* trow) {
+    // lanes 0 (and 1) have no lane - 1 (- 2): they keep their own score, which a1 = a2 = -inf discards
+    const float p1 = dpp<0x138>(prev, prev);          // prev of lane - 1
+    const float p2 = dpp<0x138>(p1, p1);              // prev of lane - 2
+    const float v0 = a0 + prev, v1 = a1 + p1, v2 = a2 + p2;
+    float best = fmaxf(fmaxf(v2, v1), v0);
+    int ptr = (v2 == best) ? lane - 2 : ((v1 == best) ? lane - 1 : lane);
+    if (best == -INFINITY) ptr = 0;
+    float cur;
+    if (MODE == VIT_LOOP32) {
+        const float cand = is_exit ? A.between32 + prev : -INFINITY;
+        const float m = wave_max(cand);
+        const unsigned long long mask = __ballot(is_exit && cand == m);
+        const int first = __ffsll((long long)mask) - 1;
+        if (is_entry) {
+            const bool cross = m >= v0;
+            best = cross ? m : v0;
+            ptr = cross ? first : lane;
+        }
+        cur = best + e;
+    } else if (MODE == VIT_LOOP64) {
+        const double cand = is_exit ? A.between64 + (double)prev : -(double)INFINITY;
+        const double m = wave_max(cand);
+        const unsigned long long mask = __ballot(is_exit && cand == m);
+        const int first = __ffsll((long long)mask) - 1;
+        double bestd = (double)best;
+        if (is_entry) {
+            const bool cross = m >= (double)v0;
+            bestd = cross ? m : (double)v0;
+            ptr = cross ? first : lane;
+        }
+        cur = (float)(bestd + (double)e);
+    } else {
+        cur = best + e;
+    }
+    *trow = (int8_t)ptr;
+    return cur;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -140,55 +206,31 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
     float prev = is_start ? llrow[0] + a0 : -INFINITY;
 
     // ---- recursion -----------------------------------------------------------------------------
-    float ebuf[VIT_PREFETCH];
+    // Emission scores travel one chunk of VIT_PREFETCH frames ahead: the loads of the next chunk are
+    // issued before the current chunk is processed and are first waited for a chunk later.
+    float ecur[VIT_PREFETCH], enxt[VIT_PREFETCH];
 #pragma unroll
-    for (int i = 0; i < VIT_PREFETCH; ++i) ebuf[i] = (1 + i < T) ? llrow[(int64_t)(1 + i) * LSR_LL_STRIDE] : 0.f;
-
-    for (int t0 = 1; t0 < T; t0 += VIT_PREFETCH) {
+    for (int i = 0; i < VIT_PREFETCH; ++i) {
+        const int t = 1 + i < T ? 1 + i : T - 1;
+        ecur[i] = llrow[(int64_t)t * LSR_LL_STRIDE];
+    }
+    int t0 = 1;
+    for (; t0 + VIT_PREFETCH <= T; t0 += VIT_PREFETCH) {
 #pragma unroll
         for (int i = 0; i < VIT_PREFETCH; ++i) {
-            const int t = t0 + i;
-            if (t < T) {
-                const float e = ebuf[i];
-                if (t + VIT_PREFETCH < T) ebuf[i] = llrow[(int64_t)(t + VIT_PREFETCH) * LSR_LL_STRIDE];
-                const float p1 = dpp<0x138>(-INFINITY, prev);      // prev of lane - 1
-                const float p2 = dpp<0x138>(-INFINITY, p1);        // prev of lane - 2
-                const float v0 = a0 + prev, v1 = a1 + p1, v2 = a2 + p2;
-                float best = fmaxf(fmaxf(v2, v1), v0);
-                int ptr = (v2 == best) ? lane - 2 : ((v1 == best) ? lane - 1 : lane);
-                if (best == -INFINITY) ptr = 0;
-                float cur;
-                if (MODE == VIT_LOOP32) {
-                    const float cand = is_exit ? A.between32 + prev : -INFINITY;
-                    const float m = wave_max(cand);
-                    const unsigned long long mask = __ballot(is_exit && cand == m);
-                    const int first = __ffsll((long long)mask) - 1;
-                    if (is_entry) {
-                        const bool cross = m >= v0;
-                        best = cross ? m : v0;
-                        ptr = cross ? first : lane;
-                    }
-                    cur = best + e;
-                } else if (MODE == VIT_LOOP64) {
-                    const double cand = is_exit ? A.between64 + (double)prev : -(double)INFINITY;
-                    const double m = wave_max(cand);
-                    const unsigned long long mask = __ballot(is_exit && cand == m);
-                    const int first = __ffsll((long long)mask) - 1;
-                    double bestd = (double)best;
-                    if (is_entry) {
-                        const bool cross = m >= (double)v0;
-                        bestd = cross ? m : (double)v0;
-                        ptr = cross ? first : lane;
-                    }
-                    cur = (float)(bestd + (double)e);
-                } else {
-                    cur = best + e;
-                }
-                trrow[(int64_t)t * 64] = (int8_t)ptr;
-                prev = cur;
-            }
+            const int t = t0 + VIT_PREFETCH + i < T ? t0 + VIT_PREFETCH + i : T - 1;      // clamped: no branch
+            enxt[i] = llrow[(int64_t)t * LSR_LL_STRIDE];
         }
+#pragma unroll
+        for (int i = 0; i < VIT_PREFETCH; ++i)
+            prev = vit_step<MODE>(A, prev, ecur[i], a0, a1, a2, is_entry, is_exit, lane, trrow + (int64_t)(t0 + i) * 64);
+#pragma unroll
+        for (int i = 0; i < VIT_PREFETCH; ++i) ecur[i] = enxt[i];
     }
+#pragma unroll
+    for (int i = 0; i < VIT_PREFETCH; ++i)                      // the last, partial chunk
+        if (t0 + i < T)
+            prev = vit_step<MODE>(A, prev, ecur[i], a0, a1, a2, is_entry, is_exit, lane, trrow + (int64_t)(t0 + i) * 64);
 
     // ---- termination ---------------------------------------------------------------------------
     int term;
