@@ -81,8 +81,12 @@ __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, co
 #define MP_PLD 164
 #define MP_SLOT_BINS 6       // bins per mel slot (61 slots cover the 260 non-zero weights)
 
+// The load is unconditional (clamped index): a load under a branch is waited for where the branch
+// joins, which would stall the pipeline in the iteration that issues it.
 __device__ __forceinline__ int4 mp_load_info(const int4* __restrict__ frame_info, int64_t total_frames, int64_t g) {
-    return g < total_frames ? frame_info[g] : make_int4(0, 0, 0, 0);      // empty range: all padding
+    int4 r = frame_info[g < total_frames ? g : total_frames - 1];
+    if (g >= total_frames) r.w = 0;                                        // empty range: all padding
+    return r;
 }
 
 // samples 2m, 2m+1 (m = 16 n1 + n2, n1 = 0..9) of the frame described by `info` for one lane; zero
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     __shared__ float power[MP_FRAMES][MP_PLD];
     __shared__ float part[MP_FRAMES][64];
     __shared__ unsigned int fmax_bits[MP_FRAMES];
+    __shared__ int band_s[2 * LSR_N_MELS];                      // first slot and slot count of each band
     __shared__ __attribute__((aligned(16))) cplx win_s[160];     // window pairs (w[2m], w[2m+1])
     __shared__ __attribute__((aligned(16))) cplx tw_s[10 * 16];  // W160^(n2 k1) as [k1][n2]
 
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
         const int k1 = i >> 4, m = i & 15;
         tw_s[i] = {tw160[m * 20 + 2 * k1], tw160[m * 20 + 2 * k1 + 1]};
     }
+    for (int i = lane; i < 2 * LSR_N_MELS; i += 64) band_s[i] = band_slots[i];
     // per-lane constants kept in registers across the grid-stride loop
     const cplx tw_a = {tw320[2 * lane], tw320[2 * lane + 1]};                          // bin pair k = lane
     const cplx tw_b = {tw320[2 * (64 + n2)], tw320[2 * (64 + n2) + 1]};                // bin pair k = 64 + (lane & 15)
@@ -183,7 +189,13 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
                 const cplx w = win_s[16 * n1 + n2];
                 z[n1] = {w.re * (double)xs[2 * n1], w.im * (double)xs[2 * n1 + 1]};
             }
-            // the next group's samples travel while this group is transformed
+            // The next group's samples travel while this group is transformed.  The loads must be issued
+            // after the last read of the current samples: the memory counter is in-order, so a read of
+            // `xs` placed after them would wait for the new loads as well.  The empty asm statements pin
+            // that order (the products are complete, then the loads start).
+#pragma unroll
+            for (int n1 = 0; n1 < 10; ++n1) asm volatile("" : "+v"(z[n1].re), "+v"(z[n1].im));
+            asm volatile("" ::: "memory");
             mp_load_samples(audio, info_nxt, n2, xs);
             info_cur = info_nxt;
             info_nxt = mp_load_info(frame_info, total_frames, (grp + 2 * (int64_t)gridDim.x) * MP_FRAMES + f);
@@ -260,10 +272,12 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
             part[fd][lane] = acc;
         }
         __syncthreads();
-        for (int i = lane; i < MP_FRAMES * LSR_N_MELS; i += 64) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = lane + 64 * r;
             const int fd = i / LSR_N_MELS, band = i % LSR_N_MELS;
-            if (g0 + fd < total_frames) {
-                const int first = band_slots[2 * band], count = band_slots[2 * band + 1];
+            if (i < MP_FRAMES * LSR_N_MELS && g0 + fd < total_frames) {
+                const int first = band_s[2 * band], count = band_s[2 * band + 1];
                 float m = part[fd][first];
                 for (int j = 1; j < count; ++j) m += part[fd][first + j];
                 mel[(g0 + fd) * LSR_N_MELS + band] = m;
