@@ -124,9 +124,7 @@ __device__ __forceinline__ float mp_power(double re64, double im64) {
 // untangle one bin pair (k, 160-k) of a frame from the half-size transform Z:
 // Z = Xe + i Xo (spectra of the even/odd samples), Xe = (Z[k] + conj Z[160-k]) / 2,
 // Xo = -i (Z[k] - conj Z[160-k]) / 2, X[k] = Xe + W320^k Xo, X[160-k] = conj(Xe - W320^k Xo)
-__device__ __forceinline__ void mp_untangle(const cplx* __restrict__ z, float* __restrict__ pw, int k, cplx w) {
-    const cplx zk = z[k];
-    const cplx zm = z[k == 0 ? 0 : 160 - k];
+__device__ __forceinline__ void mp_untangle(const cplx zk, const cplx zm, float* __restrict__ pw, int k, cplx w) {
     const cplx e = {0.5 * (zk.re + zm.re), 0.5 * (zk.im - zm.im)};
     const cplx d = {0.5 * (zk.re - zm.re), 0.5 * (zk.im + zm.im)};
     const cplx t = cmul(cmul_negi(d), w);
@@ -255,10 +253,22 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
         __syncthreads();
 
         // ---- stage C: real spectrum and power; every lane keeps its twiddle factors in registers -----
+        {
+            // every bin pair is read before the first power is written: one LDS round trip, not six
+            const int kb = 64 + n2, lc = lane & 3;
+            cplx zk[MP_FRAMES], zm[MP_FRAMES];
 #pragma unroll
-        for (int fc = 0; fc < MP_FRAMES; ++fc) mp_untangle(buf + fc * MP_ZLD, power[fc], lane, tw_a);
-        mp_untangle(buf + f * MP_ZLD, power[f], 64 + n2, tw_b);
-        if (lane < MP_FRAMES) mp_untangle(buf + lane * MP_ZLD, power[lane], 80, tw_c);
+            for (int fc = 0; fc < MP_FRAMES; ++fc) {
+                zk[fc] = buf[fc * MP_ZLD + lane];
+                zm[fc] = buf[fc * MP_ZLD + (lane == 0 ? 0 : 160 - lane)];
+            }
+            const cplx zbk = buf[f * MP_ZLD + kb], zbm = buf[f * MP_ZLD + 160 - kb];
+            const cplx zc = buf[lc * MP_ZLD + 80];
+#pragma unroll
+            for (int fc = 0; fc < MP_FRAMES; ++fc) mp_untangle(zk[fc], zm[fc], power[fc], lane, tw_a);
+            mp_untangle(zbk, zbm, power[f], kb, tw_b);
+            if (lane < MP_FRAMES) mp_untangle(zc, zc, power[lane], 80, tw_c);
+        }
         __syncthreads();
 
         // ---- stage D: mel filterbank.  Lane = slot (a run of <= 6 bins of one band, weights in
