@@ -87,6 +87,32 @@ void lsr_frontend_free(lsr_ctx* ctx);
                             hipGetErrorString(_e));                                           \
     } while (0)
 
+#if defined(__HIPCC__)
+// Maximum of a float over the 64 lanes of a wavefront, returned to every lane: a running maximum
+// inside each row of 16 lanes, row totals carried into the following rows, the grand total read
+// from lane 63.  The lane move is the DPP source operand of v_max_f32 (a lane without a source is
+// left as it is); the s_nop covers the two wait states between a vector write and a DPP read of
+// the same register.  Inputs must not be NaN.
+__device__ __forceinline__ float lsr_wave_max_f32(float v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#endif
+
 // launchers implemented in the kernel translation units
 int lsr_launch_mfcc(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const int64_t* sample_off_d,
                     const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d);

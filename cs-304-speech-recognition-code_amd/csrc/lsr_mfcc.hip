@@ -142,7 +142,6 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     __shared__ __attribute__((aligned(16))) cplx buf[MP_FRAMES * 10 * MP_YLD];   // Y, then reused as Z [4][161]
     __shared__ float power[MP_FRAMES][MP_PLD];
     __shared__ float part[MP_FRAMES][64];
-    __shared__ unsigned int fmax_bits[MP_FRAMES];
     __shared__ int band_s[2 * LSR_N_MELS];                      // first slot and slot count of each band
     __shared__ __attribute__((aligned(16))) cplx win_s[160];     // window pairs (w[2m], w[2m+1])
     __shared__ __attribute__((aligned(16))) cplx tw_s[10 * 16];  // W160^(n2 k1) as [k1][n2]
@@ -176,7 +175,6 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t g0 = grp * MP_FRAMES;
-        if (lane < MP_FRAMES) fmax_bits[lane] = 0u;
         const int utt_cur = info_cur.z;
 
         // ---- stage A: 10-point DFTs over n1 for fixed (frame, n2) ------------------------------
@@ -273,30 +271,46 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 
         // ---- stage D: mel filterbank.  Lane = slot (a run of <= 6 bins of one band, weights in
         // registers, float32 FMA chain); then each band adds its 1-3 slot sums in slot order ----------
+        {
+            float pv[MP_FRAMES][MP_SLOT_BINS];                 // all reads first, then the FMA chains
 #pragma unroll
-        for (int fd = 0; fd < MP_FRAMES; ++fd) {
-            const float* pw = power[fd] + slot_start;
-            float acc = sw[0] * pw[0];
+            for (int fd = 0; fd < MP_FRAMES; ++fd)
 #pragma unroll
-            for (int j = 1; j < MP_SLOT_BINS; ++j) acc = fmaf(sw[j], pw[j], acc);
-            part[fd][lane] = acc;
-        }
-        __syncthreads();
+                for (int j = 0; j < MP_SLOT_BINS; ++j) pv[fd][j] = power[fd][slot_start + j];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = lane + 64 * r;
-            const int fd = i / LSR_N_MELS, band = i % LSR_N_MELS;
-            if (i < MP_FRAMES * LSR_N_MELS && g0 + fd < total_frames) {
-                const int first = band_s[2 * band], count = band_s[2 * band + 1];
-                float m = part[fd][first];
-                for (int j = 1; j < count; ++j) m += part[fd][first + j];
-                mel[(g0 + fd) * LSR_N_MELS + band] = m;
-                atomicMax(&fmax_bits[fd], __float_as_uint(m));
+            for (int fd = 0; fd < MP_FRAMES; ++fd) {
+                float acc = sw[0] * pv[fd][0];
+#pragma unroll
+                for (int j = 1; j < MP_SLOT_BINS; ++j) acc = fmaf(sw[j], pv[fd][j], acc);
+                part[fd][lane] = acc;
             }
         }
         __syncthreads();
-        const int utt = __shfl(utt_cur, (lane & 3) * 16);          // lane l < 4 reports frame l of the group
-        if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[utt], fmax_bits[lane]);
+        // lane = band (40 lanes): the band's 1-3 slot sums of each frame in slot order, a coalesced row
+        // store per frame, and the frame maximum by a wave reduction (the energies are non-negative)
+        {
+            const int band = lane < LSR_N_MELS ? lane : 0;
+            const int first = band_s[2 * band], count = band_s[2 * band + 1];
+            float pp[MP_FRAMES][3];
+#pragma unroll
+            for (int fd = 0; fd < MP_FRAMES; ++fd)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pp[fd][j] = part[fd][first + j < 64 ? first + j : 63];
+            float fmx = 0.f;                                   // lane fd ends up with the maximum of frame fd
+#pragma unroll
+            for (int fd = 0; fd < MP_FRAMES; ++fd) {
+                float m = pp[fd][0];
+                if (count > 1) m += pp[fd][1];
+                if (count > 2) m += pp[fd][2];
+                const bool live = lane < LSR_N_MELS && g0 + fd < total_frames;
+                if (live) mel[(g0 + fd) * LSR_N_MELS + band] = m;
+                const float top = lsr_wave_max_f32(live ? m : 0.f);
+                if (lane == fd) fmx = top;
+            }
+            const int utt = __shfl(utt_cur, (lane & 3) * 16);      // lane l < 4 reports frame l of the group
+            if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[utt], __float_as_uint(fmx));
+        }
+        __syncthreads();                                       // `part` and the transform buffer are reused
     }
 }
 

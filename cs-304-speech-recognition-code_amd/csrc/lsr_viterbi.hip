@@ -91,28 +91,10 @@ __device__ __forceinline__ T wave_max(T v) {
     return lane63(v);
 }
 
-// float32 form with the lane move folded into the maximum (v_max_f32 with a DPP source; a lane
-// without a source is left as it is, which is what a running maximum needs).  The s_nop covers the
-// two wait states between a vector write and a DPP read of the same register.  Scores are never
-// NaN, so the hardware maximum needs no canonicalisation.
+// float32 form: the lane move folded into the maximum (lsr_wave_max_f32); scores are never NaN
 template <>
 __device__ __forceinline__ float wave_max<float>(float v) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return lane63(v);
+    return lsr_wave_max_f32(v);
 }
 
 // One step of the recursion for every lane: returns the new score, stores the back-pointer.
