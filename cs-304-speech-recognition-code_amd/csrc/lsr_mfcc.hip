@@ -179,12 +179,16 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 
         // ---- stage A: 10-point DFTs over n1 for fixed (frame, n2) ------------------------------
         {
+            // window pairs and stage twiddles: all twenty LDS reads are in flight before the first use
+            cplx wv[10], tv[10];
+#pragma unroll
+            for (int n1 = 0; n1 < 10; ++n1) wv[n1] = win_s[16 * n1 + n2];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) tv[k] = tw_s[16 * k + n2];
             cplx z[10];
 #pragma unroll
-            for (int n1 = 0; n1 < 10; ++n1) {
-                const cplx w = win_s[16 * n1 + n2];
-                z[n1] = {w.re * (double)xs[2 * n1], w.im * (double)xs[2 * n1 + 1]};
-            }
+            for (int n1 = 0; n1 < 10; ++n1)
+                z[n1] = {wv[n1].re * (double)xs[2 * n1], wv[n1].im * (double)xs[2 * n1 + 1]};
             // The next group's samples travel while this group is transformed.  The loads must be issued
             // after the last read of the current samples: the memory counter is in-order, so a read of
             // `xs` placed after them would wait for the new loads as well.  The empty asm statements pin
@@ -206,8 +210,8 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const cplx wo = cmul(O[k], cplx{wc[k], wsn[k]});
-                buf[(f * 10 + k) * MP_YLD + n2] = cmul(cadd(E[k], wo), tw_s[16 * k + n2]);
-                buf[(f * 10 + k + 5) * MP_YLD + n2] = cmul(csub(E[k], wo), tw_s[16 * (k + 5) + n2]);
+                buf[(f * 10 + k) * MP_YLD + n2] = cmul(cadd(E[k], wo), tv[k]);
+                buf[(f * 10 + k + 5) * MP_YLD + n2] = cmul(csub(E[k], wo), tv[k + 5]);
             }
         }
         __syncthreads();
