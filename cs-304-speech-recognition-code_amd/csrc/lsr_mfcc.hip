@@ -132,6 +132,19 @@ __device__ __forceinline__ void mp_untangle(const cplx zk, const cplx zm, float*
     if (k != 80) pw[160 - k] = mp_power(e.re - t.re, e.im - t.im);
 }
 
+// one pass's results: lane = band writes its energy of each frame (a coalesced row per frame), lanes 0..3
+// fold the frame maxima into the utterance maximum (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void mp_store_pass(float* __restrict__ mel, unsigned int* __restrict__ uttmax,
+                                              int64_t total_frames, int64_t g0, int lane, const float (&m)[MP_FRAMES],
+                                              float frame_max, int utt) {
+    if (lane < LSR_N_MELS) {
+#pragma unroll
+        for (int fd = 0; fd < MP_FRAMES; ++fd)
+            if (g0 + fd < total_frames) mel[(g0 + fd) * LSR_N_MELS + lane] = m[fd];
+    }
+    if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[utt], __float_as_uint(frame_max));
+}
+
 template <typename SAMPLE>
 __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     const SAMPLE* __restrict__ audio, const int4* __restrict__ frame_info, int64_t total_frames, int64_t n_groups,
@@ -173,6 +186,14 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     mp_load_samples(audio, info_cur, n2, xs);
     __syncthreads();
 
+    // Results of a pass (a band's energies of the four frames, the frame maxima) are written during the
+    // first stage of the NEXT pass, just before that pass issues its prefetch: the memory counter is
+    // in-order and counts stores, so stores issued at the end of a pass would be waited for at the top
+    // of the next one together with the prefetched samples.
+    float out_m[MP_FRAMES] = {0.f, 0.f, 0.f, 0.f}, out_max = 0.f;
+    int out_utt = 0;
+    int64_t out_g0 = -1;
+
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t g0 = grp * MP_FRAMES;
         const int utt_cur = info_cur.z;
@@ -196,6 +217,7 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 #pragma unroll
             for (int n1 = 0; n1 < 10; ++n1) asm volatile("" : "+v"(z[n1].re), "+v"(z[n1].im));
             asm volatile("" ::: "memory");
+            if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, out_m, out_max, out_utt);
             mp_load_samples(audio, info_nxt, n2, xs);
             info_cur = info_nxt;
             info_nxt = mp_load_info(frame_info, total_frames, (grp + 2 * (int64_t)gridDim.x) * MP_FRAMES + f);
@@ -300,22 +322,22 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
             for (int fd = 0; fd < MP_FRAMES; ++fd)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) pp[fd][j] = part[fd][first + j < 64 ? first + j : 63];
-            float fmx = 0.f;                                   // lane fd ends up with the maximum of frame fd
 #pragma unroll
             for (int fd = 0; fd < MP_FRAMES; ++fd) {
                 float m = pp[fd][0];
                 if (count > 1) m += pp[fd][1];
                 if (count > 2) m += pp[fd][2];
                 const bool live = lane < LSR_N_MELS && g0 + fd < total_frames;
-                if (live) mel[(g0 + fd) * LSR_N_MELS + band] = m;
+                out_m[fd] = m;
                 const float top = lsr_wave_max_f32(live ? m : 0.f);
-                if (lane == fd) fmx = top;
+                if (lane == fd) out_max = top;                 // lane fd keeps the maximum of frame fd
             }
-            const int utt = __shfl(utt_cur, (lane & 3) * 16);      // lane l < 4 reports frame l of the group
-            if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[utt], __float_as_uint(fmx));
+            out_utt = __shfl(utt_cur, (lane & 3) * 16);        // lane l < 4 reports frame l of the group
+            out_g0 = g0;
         }
         __syncthreads();                                       // `part` and the transform buffer are reused
     }
+    if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, out_m, out_max, out_utt);
 }
 
 #define FN_FRAMES 64
