@@ -106,6 +106,21 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.lsr_emission_batch(fresh, ctypes.c_void_p(x.data_ptr()), 64, ctypes.c_void_p(x.data_ptr())) == -4   # no model yet
     assert lib.lsr_ctx_destroy(fresh) == 0
     assert lib.lsr_ctx_create(99, ctypes.byref(fresh)) != 0
+    # entry points of the rows around the path
+    p = ctypes.c_void_p(x.data_ptr())
+    assert lib.lsr_separation_scan(eng.ctx, null, 0, p, p, 1, 10, 160, 0.06, 0.01, 2, 9, p, p, p, p, null, null) == -1
+    assert lib.lsr_separation_scan(eng.ctx, p, 0, p, p, 1, 10, 300, 0.06, 0.01, 2, 9, p, p, p, p, null, null) == -3
+    assert b"frame_size" in lib.lsr_last_error(eng.ctx)
+    assert lib.lsr_separation_scan(eng.ctx, p, 0, p, p, 0, 10, 160, 0.06, 0.01, 2, 9, p, p, p, p, null, null) == -1
+    assert lib.lsr_gather_segments(eng.ctx, p, 3, p, p, 1, 10, p) == -1          # element size must be 2 or 4
+    assert lib.lsr_gather_segments(eng.ctx, p, 4, p, p, 0, 10, p) == -1
+    pen = (ctypes.c_double * 2)(-100.0, float("nan"))
+    wide = (ctypes.c_int32 * 2)(0, 0)
+    assert lib.lsr_decode_loop_sweep(eng.ctx, p, p, 1, 64, 64, pen, wide, 2, null, p, p, 16) == -1
+    assert b"NaN" in lib.lsr_last_error(eng.ctx)
+    assert lib.lsr_decode_loop_sweep(eng.ctx, p, p, 1, 64, 64, pen, wide, 0, null, p, p, 16) == -1
+    assert lib.lsr_accumulate_stats(eng.ctx, p, p, 64, 0, p, p, p) == -3
+    assert lib.lsr_accumulate_stats(eng.ctx, p, p, 64, 5000, p, p, p) == -3
 
 
 def test_sixty_four_state_chain_and_limit():
