@@ -76,6 +76,45 @@ void run_mix(int blocks_per_cu) {
     hipFree(out);
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (256 MACs), one accumulator value per lane
+template <int NACC>
+__global__ __launch_bounds__(256) void k4(double* out, int iters, double a0, double b0) {
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    double a = a0 + threadIdx.x * 1e-9, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC>
+void run4(int blocks_per_cu) {
+    const int cus = 256, iters = 40000;
+    double* out;
+    hipMalloc(&out, sizeof(double) * cus * blocks_per_cu * 256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k4<NACC>, dim3(cus * blocks_per_cu), dim3(256), LDS_PER_BLOCK, 0, out, iters, 1.0, 0.5);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        double flops = 512.0 * NACC * iters * (double)cus * blocks_per_cu * 4;
+        if (rep == 2)
+            printf("4x4x4_4b nacc=%d waves/SIMD=%d  %.3f ms  %.1f TFLOP/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", NACC,
+                   blocks_per_cu, ms, flops / ms / 1e9, ms * 1e-3 * 2.4e9 / (NACC * (double)iters * blocks_per_cu));
+    }
+    hipFree(out);
+}
+
 template <int NACC>
 void run(int blocks_per_cu, int cus = 256) {
     const int iters = 40000;
@@ -105,6 +144,9 @@ int main() {
     run<8>(1);
     run<4>(2);
     run<8>(2);
+    run4<8>(1);
+    run4<8>(2);
+    run4<16>(2);
     run_mix<0, false>(2);
     run_mix<2, false>(2);
     run_mix<4, false>(2);
