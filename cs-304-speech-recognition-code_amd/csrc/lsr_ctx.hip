@@ -260,7 +260,6 @@ extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     lsr_frontend_free(ctx);
     free_ptr(ctx->d_wfrag);
-    free_ptr(ctx->d_cfrag);
     free_ptr(ctx->d_lognorm);
     free_ptr(ctx->d_logw);
     free_ptr(ctx->d_band);
@@ -301,13 +300,22 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     if (n_states < 1 || !mean || !whiten || !log_norm) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_model_upload: bad argument");
     if (n_states > 4096) return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_model_upload: %d states > 4096", n_states);
     const int D = LSR_DIM;
-    // one all-zero row tile past the end: the kernel prefetches one tile ahead without a bounds test
-    std::vector<double> frag(((size_t)n_states * LSR_JTILES + 1) * LSR_KSTEPS * 64, 0.0);
-    std::vector<double> cinit(((size_t)n_states * LSR_JTILES + 1) * 64 * 4, 0.0);
     bool triangular = true;          // zero above the diagonal: feature k only feeds components j <= k
+    for (int s = 0; s < n_states && triangular; ++s)
+        for (int k = 0; k < D; ++k)
+            for (int j = k + 1; j < D; ++j)
+                if (whiten[((size_t)s * D + k) * D + j] != 0.0) triangular = false;
+    // A operands of v_mfma_f64_4x4x4_4b_f64: for output rows 4 jb .. 4 jb + 3 and features 4 kb .. 4 kb + 3 the
+    // 16 values [kk][i] = U[4 kb + kk][4 jb + i] (every lane reads the entry of its k = lane >> 4 and
+    // i = lane & 3).  Feature 39 is the constant 1 the kernel appends to every frame and carries
+    // -(mean U): the offset of the whitened vector comes out of the matrix product.  The blocks of a
+    // state are stored in the order the kernel uses them (row blocks ascending, features ascending;
+    // a triangular U only has the blocks with kb >= jb, 55 padded to 56); 20 zero blocks past the
+    // end let the kernel read ahead without a bounds test.
+    const int slots = triangular ? LSR_TRI_SLOTS : LSR_JBLOCKS * LSR_KSTEPS;
+    std::vector<double> frag(((size_t)n_states * slots + 20) * 16, 0.0);
     for (int s = 0; s < n_states; ++s) {
-        // c[j] = sum_k mean[k] U[k][j] (extended precision, rounded once); lane l, register r of the
-        // C tile of row tile a holds row 16a + (l >> 4) + 4r
+        // c[j] = sum_k mean[k] U[k][j] (extended precision, rounded once)
         double c[LSR_DIM];
         for (int j = 0; j < D; ++j) {
             long double acc = 0.0L;
@@ -315,28 +323,20 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
                 acc += (long double)mean[(size_t)s * D + k] * (long double)whiten[((size_t)s * D + k) * D + j];
             c[j] = -(double)acc;
         }
-        for (int a = 0; a < LSR_JTILES; ++a)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * a + (lane >> 4) + 4 * r;
-                    if (j < D) cinit[(((size_t)s * LSR_JTILES + a) * 64 + lane) * 4 + r] = c[j];
-                }
-        for (int k = 0; k < D; ++k)
-            for (int j = k + 1; j < D; ++j)
-                if (whiten[((size_t)s * D + k) * D + j] != 0.0) triangular = false;
-        for (int a = 0; a < LSR_JTILES; ++a)
-            for (int ks = 0; ks < LSR_KSTEPS; ++ks)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int k = 4 * ks + (lane >> 4), j = 16 * a + (lane & 15);
-                    if (k < D && j < D)
-                        frag[(((size_t)s * LSR_JTILES + a) * LSR_KSTEPS + ks) * 64 + lane] =
-                            whiten[((size_t)s * D + k) * D + j];
-                }
+        int v = 0;
+        for (int jb = 0; jb < LSR_JBLOCKS; ++jb)
+            for (int kb = triangular ? jb : 0; kb < LSR_KSTEPS; ++kb, ++v)
+                for (int kk = 0; kk < 4; ++kk)
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = 4 * kb + kk, j = 4 * jb + i;
+                        double val = 0.0;
+                        if (j < D) val = k < D ? whiten[((size_t)s * D + k) * D + j] : c[j];
+                        frag[(((size_t)s * slots + v) * 4 + kk) * 4 + i] = val;
+                    }
     }
     ctx->whiten_triangular = triangular;
     int rc;
     if ((rc = upload(ctx, &ctx->d_wfrag, frag.data(), frag.size(), "whitening fragments"))) return rc;
-    if ((rc = upload(ctx, &ctx->d_cfrag, cinit.data(), cinit.size(), "mean offsets"))) return rc;
     if ((rc = upload(ctx, &ctx->d_lognorm, log_norm, (size_t)n_states, "log normalisers"))) return rc;
     ctx->n_states = n_states;
     ctx->n_mix = 1;

@@ -2,21 +2,27 @@
 //
 //   ll[f][s] = float32( -0.5 * (log_norm[s] + sum_j ( sum_k (x[f][k] - mean[s][k]) * U[s][k][j] )^2 ) )
 //
-// evaluated as sum_j ( sum_k x[f][k] U[s][k][j] - c[s][j] )^2 with c = mean U precomputed on the
-// host: the accumulators start at -c, so the matrix unit does all the arithmetic of the
-// whitening (float64 vector adds would compete with the float64 MFMAs for the same pipe).
+// evaluated as sum_j ( sum_k x~[f][k] U~[s][k][j] )^2 with x~ = [x, 1] and U~ = [U; -(mean U)] (the
+// offset c = mean U is computed on the host in extended precision): the matrix unit does all the
+// arithmetic of the whitening, float64 vector adds would compete with the MFMAs for the same pipe.
 //
 // The work is the list of (64-frame tile, state) pairs in tile-major order.  The grid is persistent
 // (two workgroups of four wavefronts per compute unit) and every wavefront takes an equal
 // contiguous share of that list, so all wavefronts finish together whatever the batch size; a
 // share is a few runs of consecutive states of one tile.  For a run the wavefront holds the
-// tile's 64 frames (4 column tiles of 16) as B operands in registers.  A state is three row tiles
-// of 16 whitened components; a row tile is k-steps ks_begin[a]..9 of v_mfma_f64_16x16x4_f64 for
-// each of the 4 frame tiles, with A = U_s^T fragments (coalesced 512-byte loads from the
-// pre-swizzled table built by lsr_model_upload, fetched one row tile ahead of their use).  The
-// accumulators of a row tile are squared and summed in-lane; after the third tile the four
-// 16-lane groups (rows of the C tiles) are folded so that lane l holds the score of frame l,
-// which goes to the wavefront's LDS tile and, at the end of the run, to memory row by row.
+// tile's 64 frames (4 column groups of 16) as B operands in registers.
+//
+// The matrix instruction is v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products, here the
+// same 4 rows x 4 features block of U~ against four groups of 4 frames.  It has the MAC rate of the
+// 16 x 16 x 4 form, and its 4 x 4 granularity fits a triangular U: with U zero above the diagonal
+// (TRI), row block jb only needs feature blocks kb >= jb, 55 of 100 blocks.  Lane l supplies
+// A[k = l >> 4][i = l & 3] (the same for its four frame groups), B[k = l >> 4][frame l & 15] and
+// receives row i = l >> 4 of frame l & 15; A values are fetched one row block ahead of their use
+// from the table built by lsr_model_upload (16 distinct values per block: the loads of a wavefront
+// coalesce into one 128-byte line).  The accumulators of a row block are squared and summed
+// in-lane; after the last block the four 16-lane groups (rows) are folded so that lane l holds the
+// score of frame l, which goes to the wavefront's LDS tile and, at the end of the run, to memory
+// row by row.
 //
 // Every other vector instruction takes issue slots from the float64 MFMAs (they share the
 // double-precision pipe), so the loop keeps them to the 40 squares, the fold and the conversion.
@@ -24,12 +30,7 @@
 // Mixtures: with n_mix > 1 the n_states Gaussians are n_states / n_mix states of n_mix components
 // each; consecutive components are folded with a sequential float64 log-add-exp of
 // log w + log N (the order NumPy's np.logaddexp loop uses) before the float32 rounding.
-//
-// ks_begin lets a lower-triangular whitening matrix (zero above the diagonal) skip the
-// all-zero k-steps of the second and third row tile; a dense matrix uses 0, 0, 0.
 #include "lsr_internal.h"
-
-typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define EM_WAVES 4
 
@@ -49,10 +50,10 @@ __device__ __forceinline__ void em_swap16(double& a, double& b) {
     b = __hiloint2double(hi[1], lo[1]);
 }
 
-template <int KB1, int KB2>
+template <bool TRI>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
-    const v4d* __restrict__ cfrag, const double* __restrict__ lognorm, const double* __restrict__ logw,
+    const double* __restrict__ lognorm, const double* __restrict__ logw,
     int n_states, int n_mix, float* __restrict__ ll) {
     // [frame][state ^ frame]: the XOR keeps both the per-frame writes and the per-row reads
     // on distinct LDS banks without padding (4 x 16 KiB = the 64 KiB static limit)
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
         const int64_t f0 = t * 64;
         p += c1 - c0;
 
-        // B-operand source: x[frame 16q + col][k = 4ks + grp], zero beyond the batch / beyond k = 38
+        // B-operand source: x~[frame 16q + col][k = 4ks + grp]; frames beyond the batch are zero
         double x[4][LSR_KSTEPS];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -85,60 +86,57 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
 #pragma unroll
             for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
                 const int k = 4 * ks + grp;
-                x[q][ks] = (live && k < LSR_DIM) ? (double)row[k] : 0.0;
+                x[q][ks] = k < LSR_DIM ? (live ? (double)row[k] : 0.0) : 1.0;      // feature 39 is the constant
             }
         }
 
-        // [state][row tile][k-step][lane] and [state][row tile][lane] (-c for the lane's 4 rows of the
-        // C tile); both tables end with one zero tile, so the look-ahead below needs no bounds test
+        // A values are a stream: the blocks of a state in the order of their use (row block by row block,
+        // features ascending), EM_SLOTS per state, states back to back.  EM_RING of them are in flight:
+        // the register of a block is refilled with the block EM_RING places further down the stream as
+        // soon as its four MFMAs are issued, which is ~1000 cycles before that block is needed.
+        constexpr int SLOTS = TRI ? LSR_TRI_SLOTS : LSR_JBLOCKS * LSR_KSTEPS;
+        constexpr int RING = TRI ? 14 : 20;                                    // divides SLOTS
         const int s_begin = c0 * n_mix, s_end = c1 * n_mix;
-        double wc[LSR_KSTEPS], wn[LSR_KSTEPS];
+        const int a_idx = (lane >> 4) * 4 + (lane & 3);
+        double w[RING];
         {
-            const double* src = wfrag + (size_t)s_begin * (LSR_JTILES * LSR_KSTEPS * 64);
+            const double* src = wfrag + (size_t)s_begin * (SLOTS * 16) + a_idx;
 #pragma unroll
-            for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = src[ks * 64 + lane];
+            for (int v = 0; v < RING; ++v) w[v] = src[v * 16];
         }
-        v4d cc = cfrag[(size_t)s_begin * (LSR_JTILES * 64) + lane], cn;
 
         double run = 0.0;          // log-sum of the components of the current state seen so far
         int mix = 0;
         for (int s = s_begin; s < s_end; ++s) {
+            const double* ahead = wfrag + ((size_t)s * SLOTS + RING) * 16 + a_idx;      // wave-uniform base
             double ss[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int a = 0; a < LSR_JTILES; ++a) {
-                const int kb = a == 0 ? 0 : (a == 1 ? KB1 : KB2);
-                // fetch the fragments of the next row tile (next state after the third tile)
-                {
-                    const int nxt = s * LSR_JTILES + a + 1;                      // wave-uniform
-                    const double* src = wfrag + (size_t)nxt * (LSR_KSTEPS * 64);
-                    const int nkb = a == 0 ? KB1 : (a == 1 ? KB2 : 0);
+            for (int jb = 0; jb < LSR_JBLOCKS; ++jb) {
+                const int k0 = TRI ? jb : 0;
+                const int v0 = TRI ? jb * LSR_KSTEPS - jb * (jb - 1) / 2 - jb : jb * LSR_KSTEPS - k0;    // stream place of (jb, kb) is v0 + kb
+                double acc[4];
 #pragma unroll
-                    for (int ks = 0; ks < LSR_KSTEPS; ++ks)
-                        if (ks >= nkb) wn[ks] = src[ks * 64 + lane];
-                    cn = cfrag[(size_t)nxt * 64 + lane];
-                }
-                v4d acc[4];
+                for (int kb = 0; kb < LSR_KSTEPS; ++kb) {
+                    if (kb >= k0) {
+                        const int v = v0 + kb;
+                        const double wv = w[v % RING];
+                        if (kb == k0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = cc;
+                            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb], 0.0, 0, 0, 0);
+                        } else {
 #pragma unroll
-                for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
-                    if (ks >= kb) {
-                        const double w = wc[ks];
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[0][ks], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[1][ks], acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[2][ks], acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, x[3][ks], acc[3], 0, 0, 0);
+                            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb], acc[q], 0, 0, 0);
+                        }
+                        // the table ends with RING zero blocks, so the look-ahead needs no bounds test
+                        if ((v + RING) % SLOTS < (TRI ? 55 : SLOTS)) w[v % RING] = ahead[v * 16];
                     }
                 }
-                // rows 40..47 (registers 2 and 3 of the third tile) are padding: always zero
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int r = 0; r < (a == 2 ? 2 : 4); ++r) ss[q] = fma(acc[q][r], acc[q][r], ss[q]);
-#pragma unroll
-                for (int ks = 0; ks < LSR_KSTEPS; ++ks) wc[ks] = wn[ks];
-                cc = cn;
+                for (int q = 0; q < 4; ++q) ss[q] = fma(acc[q], acc[q], ss[q]);
             }
+            // the padding places of the stream carry no block, but their turn to refill a register remains
+#pragma unroll
+            for (int v = TRI ? 55 : SLOTS; v < SLOTS; ++v) w[v % RING] = ahead[v * 16];
             const double ln = lognorm[s];
             // fold the four lane groups (rows of the C tiles) so that group g keeps frame tile g
             em_swap32(ss[0], ss[2]);
@@ -191,11 +189,11 @@ int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames
     if (blocks > 2 * (int64_t)ctx->n_cus) blocks = 2 * (int64_t)ctx->n_cus;
     lsr_prof_begin(ctx, LSR_K_EMISSION);
     if (ctx->whiten_triangular)
-        hipLaunchKernelGGL((lsr_emission_kernel<4, 8>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
-                           feats_d, total_frames, ctx->d_wfrag, (const v4d*)ctx->d_cfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
+        hipLaunchKernelGGL((lsr_emission_kernel<true>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
+                           feats_d, total_frames, ctx->d_wfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
     else
-        hipLaunchKernelGGL((lsr_emission_kernel<0, 0>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
-                           feats_d, total_frames, ctx->d_wfrag, (const v4d*)ctx->d_cfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
+        hipLaunchKernelGGL((lsr_emission_kernel<false>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
+                           feats_d, total_frames, ctx->d_wfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_emission_kernel");
     return LSR_OK;

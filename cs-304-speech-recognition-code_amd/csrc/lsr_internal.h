@@ -10,7 +10,8 @@
 #include "lsr_hip.h"
 
 #define LSR_KPAD 40          // feature dimension padded to a multiple of the MFMA k-step (4)
-#define LSR_JTILES 3         // whitened components padded to 3 tiles of 16
+#define LSR_JBLOCKS 10       // whitened components padded to 10 blocks of 4
+#define LSR_TRI_SLOTS 56     // blocks per state of a triangular whitening matrix (55) rounded up
 #define LSR_KSTEPS 10        // LSR_KPAD / 4
 
 struct lsr_buffer {
@@ -35,9 +36,8 @@ struct lsr_ctx {
 
     // model (device)
     int n_states = 0;
-    double* d_wfrag = nullptr;       // [S][3][10][64]  MFMA A-operand fragments of U^T
+    double* d_wfrag = nullptr;       // [S][blocks in order of use][4 k][4 rows]  MFMA A operands of [U; -(mean U)]
     bool whiten_triangular = false;  // every whitening matrix is zero above the diagonal
-    double* d_cfrag = nullptr;       // [S][3][64][4]  -(mean U)[j] laid out as the initial MFMA accumulator
     double* d_lognorm = nullptr;     // [S]
     int n_mix = 1;                   // components per state (n_states counts components)
     double* d_logw = nullptr;        // [S] log mixture weights (n_mix > 1 only)
