@@ -331,7 +331,8 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
                         const int k = 4 * kb + kk, j = 4 * jb + i;
                         double val = 0.0;
                         if (j < D) val = k < D ? whiten[((size_t)s * D + k) * D + j] : c[j];
-                        frag[(((size_t)s * slots + v) * 4 + kk) * 4 + i] = val;
+                        // places 2p and 2p + 1 are interleaved: [p][kk][i][place & 1]
+                        frag[(((((size_t)s * slots + v) / 2) * 4 + kk) * 4 + i) * 2 + (v & 1)] = val;
                     }
     }
     ctx->whiten_triangular = triangular;

@@ -34,6 +34,8 @@
 
 #define EM_WAVES 4
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 // Exchange the upper 32 lanes of a with the lower 32 lanes of b (v_permlane32_swap), and the odd
 // 16-lane rows of a with the even rows of b (v_permlane16_swap): after the exchange a + b adds
 // lane pairs 32 (16) apart, the first operand's sums landing in the lower (even) half.
@@ -95,20 +97,21 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
         // the register of a block is refilled with the block EM_RING places further down the stream as
         // soon as its four MFMAs are issued, which is ~1000 cycles before that block is needed.
         constexpr int SLOTS = TRI ? LSR_TRI_SLOTS : LSR_JBLOCKS * LSR_KSTEPS;
-        constexpr int RING = TRI ? 14 : 20;                                    // divides SLOTS
+        constexpr int RING = TRI ? 14 : 20;                                    // divides SLOTS, even
         const int s_begin = c0 * n_mix, s_end = c1 * n_mix;
         const int a_idx = (lane >> 4) * 4 + (lane & 3);
-        double w[RING];
+        // two consecutive places of the stream are interleaved in memory: one 16-byte load fills two registers
+        v2d w[RING / 2];
         {
-            const double* src = wfrag + (size_t)s_begin * (SLOTS * 16) + a_idx;
+            const v2d* src = (const v2d*)wfrag + (size_t)s_begin * (SLOTS * 8) + a_idx;
 #pragma unroll
-            for (int v = 0; v < RING; ++v) w[v] = src[v * 16];
+            for (int v = 0; v < RING / 2; ++v) w[v] = src[v * 16];
         }
 
         double run = 0.0;          // log-sum of the components of the current state seen so far
         int mix = 0;
         for (int s = s_begin; s < s_end; ++s) {
-            const double* ahead = wfrag + ((size_t)s * SLOTS + RING) * 16 + a_idx;      // wave-uniform base
+            const v2d* ahead = (const v2d*)wfrag + ((size_t)s * SLOTS + RING) * 8 + a_idx;      // wave-uniform base
             double ss[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int jb = 0; jb < LSR_JBLOCKS; ++jb) {
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
                 for (int kb = 0; kb < LSR_KSTEPS; ++kb) {
                     if (kb >= k0) {
                         const int v = v0 + kb;
-                        const double wv = w[v % RING];
+                        const double wv = w[(v % RING) / 2][v % 2];
                         if (kb == k0) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb], 0.0, 0, 0, 0);
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
                             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb], acc[q], 0, 0, 0);
                         }
                         // the table ends with RING zero blocks, so the look-ahead needs no bounds test
-                        if ((v + RING) % SLOTS < (TRI ? 55 : SLOTS)) w[v % RING] = ahead[v * 16];
+                        if (v % 2 == 1) w[(v % RING) / 2] = ahead[(v / 2) * 16];          // both places of the pair are used
                     }
                 }
 #pragma unroll
@@ -136,7 +139,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
             }
             // the padding places of the stream carry no block, but their turn to refill a register remains
 #pragma unroll
-            for (int v = TRI ? 55 : SLOTS; v < SLOTS; ++v) w[v % RING] = ahead[v * 16];
+            for (int v = TRI ? 55 : SLOTS; v < SLOTS; ++v)
+                if (v % 2 == 1) w[(v % RING) / 2] = ahead[(v / 2) * 16];
             const double ln = lognorm[s];
             // fold the four lane groups (rows of the C tiles) so that group g keeps frame tile g
             em_swap32(ss[0], ss[2]);
