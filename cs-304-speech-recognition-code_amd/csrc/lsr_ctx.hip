@@ -309,8 +309,8 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     // 16 values [kk][i] = U[4 kb + kk][4 jb + i] (every lane reads the entry of its k = lane >> 4 and
     // i = lane & 3).  Feature 39 is the constant 1 the kernel appends to every frame and carries
     // -(mean U): the offset of the whitened vector comes out of the matrix product.  The blocks of a
-    // state are stored in the order the kernel uses them (row blocks ascending, features ascending;
-    // a triangular U only has the blocks with kb >= jb, 55 padded to 56); 20 zero blocks past the
+    // state are stored in the order the kernel uses them (a triangular U only has the blocks with
+    // kb >= jb, 55 padded to 56); 20 zero blocks past the
     // end let the kernel read ahead without a bounds test.
     const int slots = triangular ? LSR_TRI_SLOTS : LSR_JBLOCKS * LSR_KSTEPS;
     std::vector<double> frag(((size_t)n_states * slots + 20) * 16, 0.0);
@@ -323,17 +323,25 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
                 acc += (long double)mean[(size_t)s * D + k] * (long double)whiten[((size_t)s * D + k) * D + j];
             c[j] = -(double)acc;
         }
+        // order of use: row blocks two at a time (jp, jp + 1), their feature blocks alternating
         int v = 0;
-        for (int jb = 0; jb < LSR_JBLOCKS; ++jb)
-            for (int kb = triangular ? jb : 0; kb < LSR_KSTEPS; ++kb, ++v)
-                for (int kk = 0; kk < 4; ++kk)
-                    for (int i = 0; i < 4; ++i) {
-                        const int k = 4 * kb + kk, j = 4 * jb + i;
-                        double val = 0.0;
-                        if (j < D) val = k < D ? whiten[((size_t)s * D + k) * D + j] : c[j];
-                        // places 2p and 2p + 1 are interleaved: [p][kk][i][place & 1]
-                        frag[(((((size_t)s * slots + v) / 2) * 4 + kk) * 4 + i) * 2 + (v & 1)] = val;
-                    }
+        for (int jp = 0; jp < LSR_JBLOCKS; jp += 2) {
+            const int first[2] = {triangular ? jp : 0, triangular ? jp + 1 : 0};
+            for (int t = 0; t < LSR_KSTEPS; ++t)
+                for (int h = 0; h < 2; ++h) {
+                    const int jb = jp + h, kb = first[h] + t;
+                    if (kb >= LSR_KSTEPS) continue;
+                    for (int kk = 0; kk < 4; ++kk)
+                        for (int i = 0; i < 4; ++i) {
+                            const int k = 4 * kb + kk, j = 4 * jb + i;
+                            double val = 0.0;
+                            if (j < D) val = k < D ? whiten[((size_t)s * D + k) * D + j] : c[j];
+                            // places 2p and 2p + 1 are interleaved: [p][kk][i][place & 1]
+                            frag[(((((size_t)s * slots + v) / 2) * 4 + kk) * 4 + i) * 2 + (v & 1)] = val;
+                        }
+                    ++v;
+                }
+        }
     }
     ctx->whiten_triangular = triangular;
     int rc;

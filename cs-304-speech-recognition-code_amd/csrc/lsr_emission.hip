@@ -113,29 +113,39 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
         for (int s = s_begin; s < s_end; ++s) {
             const v2d* ahead = (const v2d*)wfrag + ((size_t)s * SLOTS + RING) * 8 + a_idx;      // wave-uniform base
             double ss[4] = {0.0, 0.0, 0.0, 0.0};
+            // Row blocks are taken two at a time (jb, jb + 1) with their feature blocks interleaved: eight
+            // independent accumulator chains keep the matrix pipe fed (a chain can take a new MFMA only
+            // when its previous one has finished).  Place in the stream: pair base + 2 t (+ 1 for the second).
 #pragma unroll
-            for (int jb = 0; jb < LSR_JBLOCKS; ++jb) {
-                const int k0 = TRI ? jb : 0;
-                const int v0 = TRI ? jb * LSR_KSTEPS - jb * (jb - 1) / 2 - jb : jb * LSR_KSTEPS - k0;    // stream place of (jb, kb) is v0 + kb
-                double acc[4];
+            for (int jp = 0; jp < LSR_JBLOCKS; jp += 2) {
+                const int ka = TRI ? jp : 0, kb0 = TRI ? jp + 1 : 0;             // first feature block of each row block
+                const int na = LSR_KSTEPS - ka, nb = LSR_KSTEPS - kb0;
+                // blocks before row block jp: sum_{j < jp} (10 - j) for a triangular matrix
+                const int v_base = TRI ? jp * LSR_KSTEPS - jp * (jp - 1) / 2 : jp * LSR_KSTEPS;
+                double acc[8];
 #pragma unroll
-                for (int kb = 0; kb < LSR_KSTEPS; ++kb) {
-                    if (kb >= k0) {
-                        const int v = v0 + kb;
+                for (int t = 0; t < LSR_KSTEPS; ++t) {
+                    if (t < na) {
+                        const int v = v_base + 2 * t;
                         const double wv = w[(v % RING) / 2][v % 2];
-                        if (kb == k0) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb], 0.0, 0, 0, 0);
-                        } else {
+                        for (int q = 0; q < 4; ++q)
+                            acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][ka + t], t == 0 ? 0.0 : acc[q], 0, 0, 0);
+                        if (v % 2 == 1) w[(v % RING) / 2] = ahead[(v / 2) * 16];      // both places of the pair are used
+                    }
+                    if (t < nb) {
+                        const int v = v_base + 2 * t + 1;
+                        const double wv = w[(v % RING) / 2][v % 2];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb], acc[q], 0, 0, 0);
-                        }
-                        // the table ends with RING zero blocks, so the look-ahead needs no bounds test
-                        if (v % 2 == 1) w[(v % RING) / 2] = ahead[(v / 2) * 16];          // both places of the pair are used
+                        for (int q = 0; q < 4; ++q)
+                            acc[4 + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb0 + t], t == 0 ? 0.0 : acc[4 + q], 0, 0, 0);
+                        if (v % 2 == 1) w[(v % RING) / 2] = ahead[(v / 2) * 16];
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ss[q] = fma(acc[q], acc[q], ss[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ss[q] = fma(acc[4 + q], acc[4 + q], ss[q]);
             }
             // the padding places of the stream carry no block, but their turn to refill a register remains
 #pragma unroll

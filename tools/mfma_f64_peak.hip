@@ -144,6 +144,9 @@ int main() {
     run<8>(1);
     run<4>(2);
     run<8>(2);
+    run4<2>(2);
+    run4<4>(1);
+    run4<4>(2);
     run4<8>(1);
     run4<8>(2);
     run4<16>(2);
