@@ -194,8 +194,8 @@ def other_config(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--utts", type=int, default=UTTS_PER_GPU, help="utterances per GPU (default: the config-3 size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
