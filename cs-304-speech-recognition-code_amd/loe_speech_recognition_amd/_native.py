@@ -248,8 +248,8 @@ class Engine:
         """Upload stacked Gaussians.  By default the whitening matrices are first rotated to lower
         triangular form: U^T = Q R gives L = R^T with L L^T = U U^T, so |(x - mu) L|^2 is the same
         Mahalanobis distance (an orthogonal change of basis of the whitened vector) while the
-        device skips the k-steps that are structurally zero (18 instead of 30 MFMA groups per
-        state).  ``triangular=False`` (or LSR_DENSE_WHITEN=1) uploads SciPy's U unchanged."""
+        device skips the 4 x 4 blocks that are structurally zero (55 instead of 100 per state).
+        ``triangular=False`` (or LSR_DENSE_WHITEN=1) uploads SciPy's U unchanged."""
         if token is not None and token == self._model_token:
             return
         if triangular is None:

@@ -80,7 +80,9 @@ void lsr_host_dct_matrix(double* out13x40);           /* DCT-II, orthonormal, fi
 /* Replaces MultivariateNormal.from_means_covariances (hidden_markov_model.py:27-44): the
  * state of n_states frozen full-covariance Gaussians.  mean[S][39]; whiten[S][39][39] is
  * SciPy's U = V * diag(lambda^-1/2) with whiten[s][k][j] multiplying feature k into whitened
- * component j; log_norm[s] = 39*log(2*pi) + log|Sigma_s|.  All float64, host memory. */
+ * component j; log_norm[s] = 39*log(2*pi) + log|Sigma_s|.  All float64, host memory.  Any matrix
+ * W with W W^T = Sigma^-1 gives the same scores; when every whiten[s] is zero above the diagonal
+ * (whiten[s][k][j] == 0 for j > k) the device skips the all-zero 4 x 4 blocks (55 of 100). */
 int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, const double* whiten,
                      const double* log_norm);
 
