@@ -7,9 +7,9 @@
 // arithmetic of the whitening, float64 vector adds would compete with the MFMAs for the same pipe.
 //
 // The work is the list of (64-frame tile, state) pairs in tile-major order.  The grid is persistent
-// (two workgroups of four wavefronts per compute unit) and every wavefront takes an equal
+// (three workgroups of four wavefronts per compute unit) and every wavefront takes an equal
 // contiguous share of that list, so all wavefronts finish together whatever the batch size; a
-// share is a few runs of consecutive states of one tile.  For a run the wavefront holds the
+// share is a few runs of at most 32 consecutive states of one tile.  For a run the wavefront holds the
 // tile's 64 frames (4 column groups of 16) as B operands in registers.
 //
 // The matrix instruction is v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products, here the
@@ -33,6 +33,7 @@
 #include "lsr_internal.h"
 
 #define EM_WAVES 4
+#define EM_RUN 32             // most states of one tile a wavefront scores before it writes them out
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -52,14 +53,14 @@ __device__ __forceinline__ void em_swap16(double& a, double& b) {
     b = __hiloint2double(hi[1], lo[1]);
 }
 
-template <bool TRI>
-__global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
+template <bool TRI, bool MIX>
+__global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
     const double* __restrict__ lognorm, const double* __restrict__ logw,
     int n_states, int n_mix, float* __restrict__ ll) {
-    // [frame][state ^ frame]: the XOR keeps both the per-frame writes and the per-row reads
-    // on distinct LDS banks without padding (4 x 16 KiB = the 64 KiB static limit)
-    __shared__ float tile[EM_WAVES][64][64];
+    // [frame][(state - first state of the run) ^ frame]: the XOR keeps the per-row reads on distinct LDS
+    // banks without padding; 8 KiB per wavefront, so three workgroups fit a compute unit
+    __shared__ float tile[EM_WAVES][64][EM_RUN];
     // readfirstlane: the wavefront index (and everything derived from it) lives in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = lane & 15, grp = lane >> 4;
@@ -70,25 +71,30 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
     int64_t p = me * n_pairs / n_waves;
     const int64_t p_end = (me + 1) * n_pairs / n_waves;
 
+    int64_t loaded = -1;                                       // tile whose frames are in x[][]
+    double x[4][LSR_KSTEPS];
     while (p < p_end) {
-        // one run: columns c0..c1-1 of tile t
+        // one run: columns c0..c1-1 of tile t, at most EM_RUN of them
         const int64_t t = p / n_cols;
         const int c0 = (int)(p - t * n_cols);
-        const int c1 = (int)((int64_t)n_cols - c0 < p_end - p ? n_cols : c0 + (p_end - p));
+        int c1 = (int)((int64_t)n_cols - c0 < p_end - p ? n_cols : c0 + (p_end - p));
+        if (c1 > c0 + EM_RUN) c1 = c0 + EM_RUN;
         const int64_t f0 = t * 64;
         p += c1 - c0;
 
         // B-operand source: x~[frame 16q + col][k = 4ks + grp]; frames beyond the batch are zero
-        double x[4][LSR_KSTEPS];
+        if (t != loaded) {
+            loaded = t;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t f = f0 + 16 * q + col;
-            const bool live = f < total_frames;
-            const float* row = feats + (live ? f : 0) * LSR_DIM;
+            for (int q = 0; q < 4; ++q) {
+                const int64_t f = f0 + 16 * q + col;
+                const bool live = f < total_frames;
+                const float* row = feats + (live ? f : 0) * LSR_DIM;
 #pragma unroll
-            for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
-                const int k = 4 * ks + grp;
-                x[q][ks] = k < LSR_DIM ? (live ? (double)row[k] : 0.0) : 1.0;      // feature 39 is the constant
+                for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
+                    const int k = 4 * ks + grp;
+                    x[q][ks] = k < LSR_DIM ? (live ? (double)row[k] : 0.0) : 1.0;      // feature 39 is the constant
+                }
             }
         }
 
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
         // the register of a block is refilled with the block EM_RING places further down the stream as
         // soon as its four MFMAs are issued, which is ~1000 cycles before that block is needed.
         constexpr int SLOTS = TRI ? LSR_TRI_SLOTS : LSR_JBLOCKS * LSR_KSTEPS;
-        constexpr int RING = TRI ? 14 : 20;                                    // divides SLOTS, even
+        constexpr int RING = TRI ? 14 : 10;                                    // divides SLOTS, even
         const int s_begin = c0 * n_mix, s_end = c1 * n_mix;
         const int a_idx = (lane >> 4) * 4 + (lane & 3);
         // two consecutive places of the stream are interleaved in memory: one 16-byte load fills two registers
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
             em_swap16(v0, v1);
             const double maha = v0 + v1;
             const double lp = -0.5 * (ln + maha);
-            if (n_mix == 1) {
-                tile[wave][lane][(s ^ lane) & 63] = (float)lp;
+            if (!MIX) {
+                tile[wave][lane][((s - s_begin) ^ lane) & (EM_RUN - 1)] = (float)lp;
             } else {
                 const double v = logw[s] + lp;
                 if (mix == 0) {
@@ -174,20 +180,25 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
                 }
                 if (++mix == n_mix) {
                     const int c = s / n_mix;
-                    tile[wave][lane][(c ^ lane) & 63] = (float)run;
+                    tile[wave][lane][((c - c0) ^ lane) & (EM_RUN - 1)] = (float)run;
                     mix = 0;
                 }
             }
         }
-        // write-out of columns c0..c1-1 (and the -inf padding columns after the last state) of the
-        // wavefront's own tile, one row per instruction; only this wavefront touches tile[wave]
+        // write-out of columns c0..c1-1 of the wavefront's own tile, one row per instruction (lane = column
+        // c0 + lane); the run that ends a tile also fills the padding columns up to 64 with -inf.  Only
+        // this wavefront touches tile[wave].
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bool mine = lane >= c0 && lane < (c1 == n_cols ? 64 : c1);
-        for (int r = 0; r < 64; ++r) {
-            const float v = lane < n_cols ? tile[wave][r][(lane ^ r) & 63] : -INFINITY;
-            if (mine) ll[(f0 + r) * LSR_LL_STRIDE + lane] = v;
+        if (lane < c1 - c0) {
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r)
+                ll[(f0 + r) * LSR_LL_STRIDE + c0 + lane] = tile[wave][r][(lane ^ r) & (EM_RUN - 1)];
+        }
+        if (c1 == n_cols && n_cols + lane < LSR_LL_STRIDE) {
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) ll[(f0 + r) * LSR_LL_STRIDE + n_cols + lane] = -INFINITY;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -196,18 +207,19 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void lsr_emission_kernel(
 }
 
 int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d) {
-    // persistent grid: two resident workgroups per compute unit (64 KiB of LDS each), fewer when the
-    // batch has fewer (tile, state) pairs than that many wavefronts
+    // persistent grid: as many workgroups as fit a compute unit (three of 32 KiB of LDS and <= 168 VGPRs;
+    // two for mixtures), fewer when the batch has fewer (tile, state) pairs than that many wavefronts
+    const bool mix = ctx->n_mix > 1;
+    const int per_cu = mix ? 2 : 3;
     const int64_t pairs = (total_frames + 63) / 64 * (ctx->n_states / ctx->n_mix);
     int64_t blocks = (pairs + EM_WAVES - 1) / EM_WAVES;
-    if (blocks > 2 * (int64_t)ctx->n_cus) blocks = 2 * (int64_t)ctx->n_cus;
+    if (blocks > per_cu * (int64_t)ctx->n_cus) blocks = per_cu * (int64_t)ctx->n_cus;
+    void (*kern)(const float*, int64_t, const double*, const double*, const double*, int, int, float*) =
+        ctx->whiten_triangular ? (mix ? lsr_emission_kernel<true, true> : lsr_emission_kernel<true, false>)
+                               : (mix ? lsr_emission_kernel<false, true> : lsr_emission_kernel<false, false>);
     lsr_prof_begin(ctx, LSR_K_EMISSION);
-    if (ctx->whiten_triangular)
-        hipLaunchKernelGGL((lsr_emission_kernel<true>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
-                           feats_d, total_frames, ctx->d_wfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
-    else
-        hipLaunchKernelGGL((lsr_emission_kernel<false>), dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream,
-                           feats_d, total_frames, ctx->d_wfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream, feats_d, total_frames,
+                       ctx->d_wfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_emission_kernel");
     return LSR_OK;
