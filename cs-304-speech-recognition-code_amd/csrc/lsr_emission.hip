@@ -17,12 +17,12 @@
 // 16 x 16 x 4 form, and its 4 x 4 granularity fits a triangular U: with U zero above the diagonal
 // (TRI), row block jb only needs feature blocks kb >= jb, 55 of 100 blocks.  Lane l supplies
 // A[k = l >> 4][i = l & 3] (the same for its four frame groups), B[k = l >> 4][frame l & 15] and
-// receives row i = l >> 4 of frame l & 15; A values are fetched one row block ahead of their use
-// from the table built by lsr_model_upload (16 distinct values per block: the loads of a wavefront
-// coalesce into one 128-byte line).  The accumulators of a row block are squared and summed
-// in-lane; after the last block the four 16-lane groups (rows) are folded so that lane l holds the
-// score of frame l, which goes to the wavefront's LDS tile and, at the end of the run, to memory
-// row by row.
+// receives row i = l >> 4 of frame l & 15; A values stream through a small ring of registers from
+// the table built by lsr_model_upload (16 distinct values per block: the loads of a wavefront
+// coalesce into one or two 128-byte lines).  The accumulators of a row block are squared and
+// summed in-lane; after the last block the four 16-lane groups (rows) are folded so that lane l
+// holds the score of frame l, which goes to the wavefront's LDS tile and, at the end of the run,
+// to memory row by row.
 //
 // Every other vector instruction takes issue slots from the float64 MFMAs (they share the
 // double-precision pipe), so the loop keeps them to the 40 squares, the fold and the conversion.
@@ -98,10 +98,10 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
             }
         }
 
-        // A values are a stream: the blocks of a state in the order of their use (row block by row block,
-        // features ascending), EM_SLOTS per state, states back to back.  EM_RING of them are in flight:
-        // the register of a block is refilled with the block EM_RING places further down the stream as
-        // soon as its four MFMAs are issued, which is ~1000 cycles before that block is needed.
+        // A values are a stream: the blocks of a state in the order of their use (see the loop below),
+        // SLOTS places per state, states back to back.  RING of them are in flight: the register of a
+        // block is refilled with the block RING places further down the stream as soon as its four
+        // MFMAs are issued, which is ~900 cycles before that block is needed.
         constexpr int SLOTS = TRI ? LSR_TRI_SLOTS : LSR_JBLOCKS * LSR_KSTEPS;
         constexpr int RING = TRI ? 14 : 10;                                    // divides SLOTS, even
         const int s_begin = c0 * n_mix, s_end = c1 * n_mix;
