@@ -244,6 +244,7 @@ extern "C" int lsr_ctx_create(int device, lsr_ctx** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
     int rc = lsr_frontend_init(ctx);
+    if (rc == LSR_OK) rc = lsr_noalloc_init(ctx);
     if (rc != LSR_OK) {
         fprintf(stderr, "lsr_ctx_create: %s\n", ctx->error.c_str());
         lsr_frontend_free(ctx);

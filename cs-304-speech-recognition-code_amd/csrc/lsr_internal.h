@@ -70,6 +70,7 @@ void lsr_prof_begin(lsr_ctx* ctx, int kernel);
 void lsr_prof_end(lsr_ctx* ctx);
 int lsr_frontend_init(lsr_ctx* ctx);
 void lsr_frontend_free(lsr_ctx* ctx);
+int lsr_noalloc_init(lsr_ctx* ctx);      // resolves the device address of the static workspace (once per device)
 
 #define LSR_HIP_CHECK(ctx, expr)                                                              \
     do {                                                                                      \
@@ -116,10 +117,21 @@ __device__ __forceinline__ float lsr_wave_max_f32(float v) {
 // launchers implemented in the kernel translation units
 int lsr_launch_mfcc(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const int64_t* sample_off_d,
                     const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d);
+// intermediate buffers of the front-end: frame records int4[frames], utterance of every frame
+// int32[frames], mel energies float[frames][40], utterance maxima uint32[utterances]
+struct lsr_mfcc_ws {
+    void* frame_info;
+    int32_t* frame_utt;
+    float* mel;
+    unsigned int* uttmax;
+};
+int lsr_launch_mfcc_ws(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const int64_t* sample_off_d,
+                       const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d,
+                       const lsr_mfcc_ws& ws);
 int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d);
 int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
                             int64_t total_frames, int max_frames, float* scores_d, int8_t* paths_d,
-                            uint8_t* labels_d, int32_t* n_labels_d, int label_cap);
+                            uint8_t* labels_d, int32_t* n_labels_d, int label_cap, int8_t* tracer_d = nullptr);
 int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
                              int64_t total_frames, int max_frames, const int64_t* chain_off_d,
                              int64_t total_chain, const int32_t* chain_state_d,

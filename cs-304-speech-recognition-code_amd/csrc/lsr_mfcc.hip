@@ -491,10 +491,21 @@ int lsr_launch_mfcc(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const i
     if ((rc = lsr_reserve(ctx, &ctx->ws_mel, (size_t)total_frames * LSR_N_MELS * sizeof(float), "mel energies"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_uttmax, (size_t)n_utts * sizeof(unsigned int), "utterance maxima"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_frame_info, (size_t)total_frames * sizeof(int4), "frame records"))) return rc;
-    int4* frame_info = (int4*)ctx->ws_frame_info.ptr;
-    int32_t* frame_utt = (int32_t*)ctx->ws_frame_utt.ptr;
-    float* mel = (float*)ctx->ws_mel.ptr;
-    unsigned int* uttmax = (unsigned int*)ctx->ws_uttmax.ptr;
+    lsr_mfcc_ws ws;
+    ws.frame_info = ctx->ws_frame_info.ptr;
+    ws.frame_utt = (int32_t*)ctx->ws_frame_utt.ptr;
+    ws.mel = (float*)ctx->ws_mel.ptr;
+    ws.uttmax = (unsigned int*)ctx->ws_uttmax.ptr;
+    return lsr_launch_mfcc_ws(ctx, audio_d, audio_is_i16, sample_off_d, frame_off_d, n_utts, total_frames, feats_d, ws);
+}
+
+int lsr_launch_mfcc_ws(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const int64_t* sample_off_d,
+                       const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d,
+                       const lsr_mfcc_ws& ws) {
+    int4* frame_info = (int4*)ws.frame_info;
+    int32_t* frame_utt = ws.frame_utt;
+    float* mel = ws.mel;
+    unsigned int* uttmax = ws.uttmax;
     LSR_HIP_CHECK(ctx, hipMemsetAsync(uttmax, 0, (size_t)n_utts * sizeof(unsigned int), ctx->stream));
 
     lsr_prof_begin(ctx, LSR_K_FRAME_INDEX);

@@ -294,10 +294,15 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
     }
 }
 
-static int launch(lsr_ctx* ctx, int mode, vit_args& A, int n_utts, int64_t total_frames, int max_frames) {
-    int rc = lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * 64, "back-pointers");
-    if (rc) return rc;
-    A.tracer = (int8_t*)ctx->ws_tracer.ptr;
+// tracer_d: back-pointer table int8[total_frames][64] supplied by the caller, or NULL to use the context's workspace
+static int launch(lsr_ctx* ctx, int mode, vit_args& A, int n_utts, int64_t total_frames, int max_frames,
+                  int8_t* tracer_d = nullptr) {
+    if (!tracer_d) {
+        int rc = lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * 64, "back-pointers");
+        if (rc) return rc;
+        tracer_d = (int8_t*)ctx->ws_tracer.ptr;
+    }
+    A.tracer = tracer_d;
     A.path_cap = (max_frames + 63) / 64 * 64;
     const size_t lds = (size_t)A.path_cap + 64 * 64;
     if (lds > 160 * 1024)
@@ -317,7 +322,7 @@ static int launch(lsr_ctx* ctx, int mode, vit_args& A, int n_utts, int64_t total
 
 int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
                             int64_t total_frames, int max_frames, float* scores_d, int8_t* paths_d, uint8_t* labels_d,
-                            int32_t* n_labels_d, int label_cap) {
+                            int32_t* n_labels_d, int label_cap, int8_t* tracer_d) {
     vit_args A = {};
     A.ll = ll_d;
     A.frame_off = frame_off_d;
@@ -335,7 +340,7 @@ int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* fram
     A.labels = labels_d;
     A.n_labels = n_labels_d;
     A.label_cap = label_cap;
-    return launch(ctx, ctx->between_is_f64 ? VIT_LOOP64 : VIT_LOOP32, A, n_utts, total_frames, max_frames);
+    return launch(ctx, ctx->between_is_f64 ? VIT_LOOP64 : VIT_LOOP32, A, n_utts, total_frames, max_frames, tracer_d);
 }
 
 int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,

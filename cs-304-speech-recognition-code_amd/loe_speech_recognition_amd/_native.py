@@ -58,6 +58,7 @@ def _declare(lib) -> None:
         "lsr_mfcc_batch": (c_int, [P, P, P, P, c_int, c_int64, P]),
         "lsr_mfcc_batch_i16": (c_int, [P, P, P, P, c_int, c_int64, P]),
         "lsr_recognize_batch_i16": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
+        "lsr_recognize_batch_noalloc": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
         "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_decode_loop_sweep": (c_int, [P, P, P, c_int, c_int64, c_int, POINTER(c_double), POINTER(c_int32), c_int,
@@ -83,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "lsr_loop_set_between", "lsr_mfcc_batch", "lsr_emission_batch", "lsr_decode_loop_batch",
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
     "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures", "lsr_separation_scan",
-    "lsr_gather_segments", "lsr_decode_loop_sweep",
+    "lsr_gather_segments", "lsr_decode_loop_sweep", "lsr_recognize_batch_noalloc",
 ]
 
 
@@ -337,6 +338,16 @@ class Engine:
                                                  self._ptr(ab.frame_off), ab.n, ab.total_frames, ab.max_frames,
                                                  self._ptr(scores), self._ptr(paths), self._ptr(labels),
                                                  self._ptr(n_labels), label_cap))
+        return out
+
+    def recognize_noalloc(self, ab: AudioBatch, out):
+        """lsr_recognize_batch_noalloc into caller-provided outputs (scores, paths or None, labels, n_labels):
+        no device allocation happens inside the call (float32 audio, bounded batch size)."""
+        scores, paths, labels, n_labels = out
+        self._check(self.lib.lsr_recognize_batch_noalloc(self.ctx, self._ptr(ab.audio), self._ptr(ab.sample_off),
+                                                         self._ptr(ab.frame_off), ab.n, ab.total_frames, ab.max_frames,
+                                                         self._ptr(scores), self._ptr(paths), self._ptr(labels),
+                                                         self._ptr(n_labels), labels.shape[1]))
         return out
 
     def decode_chain(self, fb: FeatureBatch, chain_off: np.ndarray, chain_state: np.ndarray, chain_band: np.ndarray,

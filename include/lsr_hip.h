@@ -149,6 +149,21 @@ int lsr_recognize_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, const int64_t*
                             int max_frames, float* scores_d, int8_t* paths_d, uint8_t* labels_d,
                             int32_t* n_labels_d, int label_cap);
 
+/* lsr_recognize_batch (float32 audio) for callers that cannot allocate device memory: code under
+ * HIP stream capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
+ * in the reference.  Same arguments, same kernels and bit-identical outputs; every intermediate
+ * buffer lives in one static device array of about 41 MiB per GPU (held until the process ends)
+ * instead of the context's growing workspace, and the call performs no hipMalloc / hipFree.
+ * Limits: n_utts <= LSR_NOALLOC_MAX_UTTS and total_frames <= LSR_NOALLOC_MAX_FRAMES
+ * (LSR_ERR_LIMIT beyond); profiling must be off (LSR_ERR_STATE).  All calls on one GPU share the
+ * array: calls that overlap in time on one GPU (other streams, other contexts) race. */
+#define LSR_NOALLOC_MAX_FRAMES 65536
+#define LSR_NOALLOC_MAX_UTTS 4096
+int lsr_recognize_batch_noalloc(lsr_ctx* ctx, const float* audio_d, const int64_t* sample_off_d,
+                                const int64_t* frame_off_d, int n_utts, int64_t total_frames,
+                                int max_frames, float* scores_d, int8_t* paths_d, uint8_t* labels_d,
+                                int32_t* n_labels_d, int label_cap);
+
 /* Replaces HiddenMarkovModel.predict/_viterbi/_viterbi_static (hidden_markov_model.py:75-91,
  * 160-208) for a batch of per-utterance chains: isolated word models, several independent
  * models side by side (ModelCollection.predict, model_collection.py:23-28) or the stacked

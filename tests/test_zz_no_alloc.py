@@ -1,0 +1,79 @@
+"""lsr_recognize_batch_noalloc (static device workspace, no hipMalloc inside the call) against
+lsr_recognize_batch through the C ABI: scores, paths and label records bit-identical, on two calls in
+a row, the second with a smaller batch (the shared workspace keeps the first call's contents)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LABEL_CAP = 16
+
+
+def _outputs(eng, ab):
+    t = eng.torch
+    return (eng.empty((ab.n,), t.float32), eng.empty((ab.total_frames,), t.int8),
+            eng.empty((ab.n, LABEL_CAP), t.uint8), eng.empty((ab.n,), t.int32))
+
+
+def _call(eng, fn, ab, out):
+    scores, paths, labels, n_labels = out
+    P = ctypes.c_void_p
+    rc = fn(eng.ctx, P(ab.audio.data_ptr()), P(ab.sample_off.data_ptr()), P(ab.frame_off.data_ptr()), ab.n,
+            ab.total_frames, ab.max_frames, P(scores.data_ptr()), P(paths.data_ptr()), P(labels.data_ptr()),
+            P(n_labels.data_ptr()), LABEL_CAP)
+    eng.synchronize()
+    return rc
+
+
+def test_noalloc_equals_recognize_batch_twice_second_smaller():
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, synthetic
+
+    models = synthetic.load_word_models()
+    inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
+    inf._log_transition_probability_between_words = -100
+    eng = inf._bind()
+    lib = eng.lib
+    big, _ = synthetic.batch(3, 96, 4, start=300)
+    small, _ = synthetic.batch(2, 17, 1, start=40)
+    for sigs in (big, small):
+        ab = eng.audio_batch([np.asarray(s, dtype=np.float32) for s in sigs])
+        ref, got = _outputs(eng, ab), _outputs(eng, ab)
+        for o in got:
+            o.fill_(0x5A if o.dtype != eng.torch.float32 else 1.0)
+        assert _call(eng, lib.lsr_recognize_batch, ab, ref) == 0
+        assert _call(eng, lib.lsr_recognize_batch_noalloc, ab, got) == 0, lib.lsr_last_error(eng.ctx)
+        for r, g in zip(ref, got):
+            r, g = r.cpu().numpy(), g.cpu().numpy()
+            if r.ndim == 2:                      # label records: only the first n_labels entries are written
+                n = ref[3].cpu().numpy()
+                for i in range(r.shape[0]):
+                    assert np.array_equal(r[i, :min(n[i], LABEL_CAP)], g[i, :min(n[i], LABEL_CAP)])
+            else:
+                assert np.array_equal(r.view(np.uint8), g.view(np.uint8))
+        assert (ref[3].cpu().numpy() > 0).all()
+
+
+def test_noalloc_rejects_batches_beyond_the_static_workspace():
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, synthetic
+
+    models = synthetic.load_word_models()
+    inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
+    eng = inf._bind()
+    sigs, _ = synthetic.batch(2, 4, 1)
+    ab = eng.audio_batch([np.asarray(s, dtype=np.float32) for s in sigs])
+    out = _outputs(eng, ab)
+    P = ctypes.c_void_p
+    args = [P(ab.audio.data_ptr()), P(ab.sample_off.data_ptr()), P(ab.frame_off.data_ptr())]
+    outs = [P(o.data_ptr()) for o in out]
+    # sizes beyond the limits are refused before anything is launched
+    assert eng.lib.lsr_recognize_batch_noalloc(eng.ctx, *args, 4097, 60000, 100, *outs, LABEL_CAP) == -3
+    assert eng.lib.lsr_recognize_batch_noalloc(eng.ctx, *args, 4, 65537, 100, *outs, LABEL_CAP) == -3
+    assert b"static workspace" in eng.lib.lsr_last_error(eng.ctx)
+    eng.profile_enable(True)
+    try:
+        assert eng.lib.lsr_recognize_batch_noalloc(eng.ctx, *args, ab.n, ab.total_frames, ab.max_frames, *outs,
+                                                   LABEL_CAP) == -4
+    finally:
+        eng.profile_enable(False)
