@@ -7,7 +7,8 @@ audio resident in HBM, one process per GPU.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step is one pass of the hot path (audio -> MFCC -> emission scores -> Viterbi -> label
-records [-> all-gather of the label records when N > 1]) over this rank's 10 000 clips.
+records [-> all-gather of the label records when N > 1]) over this rank's clips: 10 000 per GPU
+(weak scaling, the default) or one corpus of 10 000 sharded over the GPUs (--scaling strong).
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -40,17 +41,41 @@ CONFIGS = {
 }
 D = 39
 FP64_MATRIX_PEAK_TFLOPS = 78.6       # MI355X dense FP64 matrix (= vector) peak, AMD datasheet
-CPU_SAMPLE = 48
-POOL = 16
+HBM_PEAK_GBPS = 8000.0               # HBM3E, MI355X
+CPU_SAMPLE = 208                     # clips of the workload timed on the host cores (after a warm-up)
+CPU_SINGLE = 8                       # clips of the single-core run
+CPU_WARMUP_PER_WORKER = 1
+
+
+def host_workers() -> int:
+    """Processes / threads this job may use: the box's CPU share (exported as OMP_NUM_THREADS on the GPU
+    boxes, where os.cpu_count() shows the whole machine), never more than the logical CPUs."""
+    n = os.cpu_count() or 1
+    for key in ("LSR_BENCH_WORKERS", "OMP_NUM_THREADS"):
+        v = os.environ.get(key)
+        if v and v.isdigit() and int(v) > 0:
+            return min(n, int(v))
+    return n
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def _gen(args):
     return synthetic.batch(*args)
 
 
-def generate(rank: int, count: int, workers: int, config_id: int = CONFIG_ID, digits=N_DIGITS):
+def generate(first: int, count: int, workers: int, config_id: int = CONFIG_ID, digits=N_DIGITS):
+    """Clips first .. first + count - 1 of a configuration (each clip has its own seed)."""
     chunk = 240
-    jobs = [(config_id, min(chunk, count - s), digits, rank * count + s) for s in range(0, count, chunk)]
+    jobs = [(config_id, min(chunk, count - s), digits, first + s) for s in range(0, count, chunk)]
     with mp.get_context("fork").Pool(workers) as pool:
         parts = pool.map(_gen, jobs)
     return [s for p in parts for s in p[0]], [d for p in parts for d in p[1]]
@@ -80,21 +105,38 @@ def _cpu_predict(model_arrays, item):
 
 
 def cpu_baseline(signals, truth, workers: int):
+    """The CPU path on a bounded sample of the workload: a warm-up (one clip per worker, untimed), then
+    CPU_SAMPLE clips fanned out one pool task per digit string on `workers` processes, then CPU_SINGLE
+    clips on one process for the per-core rate."""
     arrays = synthetic.load_word_arrays()
-    labeled = synthetic.group_by_label(signals, truth)
-    t0 = time.perf_counter()
+    n_warm = CPU_WARMUP_PER_WORKER * workers
+    warm = [(truth[i], [signals[i]]) for i in range(CPU_SAMPLE, min(CPU_SAMPLE + n_warm, len(signals)))]
+    labeled = synthetic.group_by_label(signals[:CPU_SAMPLE], truth[:CPU_SAMPLE])
+    fn = functools.partial(_cpu_predict, arrays)
     with mp.get_context("fork").Pool(workers) as pool:
-        res = pool.map(functools.partial(_cpu_predict, arrays), list(labeled.items()))
-    wall = time.perf_counter() - t0
-    decoded = {}
-    for label, out, _, _ in res:
-        decoded[label] = out
+        pool.map(fn, warm, chunksize=1)
+        t0 = time.perf_counter()
+        res = pool.map(fn, list(labeled.items()), chunksize=1)
+        wall = time.perf_counter() - t0
+    n = sum(len(v) for v in labeled.values())
+    decoded = {label: out for label, out, _, _ in res}
     cpu_s = sum(r[2] + r[3] for r in res)
-    return {"value": len(signals) / wall, "unit": "utterances/s", "cores": workers, "kind": "port",
-            "sample": f"{len(signals)} of the workload's four-digit clips, oracle with the reference's per-(frame,state) "
-                      f"SciPy logpdf loop, one pool task per digit string on {workers} processes; "
-                      f"{cpu_s / len(signals):.3f} CPU-s per utterance ({sum(r[2] for r in res) / len(signals) * 1e3:.1f} ms MFCC)",
-            "per_core": len(signals) / cpu_s}, decoded, labeled
+    mfcc_s = sum(r[2] for r in res)
+    _cpu_predict(arrays, (truth[0], [signals[0]]))                       # warm this process
+    t0 = time.perf_counter()
+    single = _cpu_predict(arrays, ("single", list(signals[CPU_SAMPLE:CPU_SAMPLE + CPU_SINGLE])))
+    single_wall = time.perf_counter() - t0
+    n_single = len(signals[CPU_SAMPLE:CPU_SAMPLE + CPU_SINGLE])
+    rec = {"value": n / wall, "unit": "utterances/s", "cores": workers, "kind": "port",
+           "sample": f"{n} of the workload's four-digit clips after a warm-up of {len(warm)}: oracle with the reference's "
+                     f"per-(frame,state) SciPy logpdf loop, one pool task per digit string on {workers} processes "
+                     f"({wall:.1f} s wall, {cpu_s / n:.3f} CPU-s per utterance of which {mfcc_s / n * 1e3:.1f} ms MFCC); "
+                     f"single-core run: {n_single} clips in {single_wall:.1f} s",
+           "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "n_utterances": n,
+           "mfcc_ms_per_utterance": mfcc_s / n * 1e3, "decode_ms_per_utterance": (cpu_s - mfcc_s) / n * 1e3,
+           "single_core_utterances_per_s": n_single / single_wall if n_single else None,
+           "per_core_utterances_per_s": n / cpu_s}
+    return rec, decoded
 
 
 def _setup(args):
@@ -124,8 +166,8 @@ def other_config(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cfg = CONFIGS[args.config]
     utts = args.utts if args.utts != UTTS_PER_GPU else cfg["utts"]
-    workers = max(1, POOL // max(1, min(world, 8)))
-    sigs, truth = generate(rank, utts, workers, args.config, cfg["digits"])
+    workers = max(1, host_workers() // max(1, min(world, 8)))
+    sigs, truth = generate(rank * utts, utts, workers, args.config, cfg["digits"])
     torch, dist, eng, rank, world, backend = _setup(args)
     from loe_speech_recognition_amd import (MFCC, HiddenMarkovModelInference, HiddenMarkovModelTrainContinuous,
                                             ModelCollection, _native)
@@ -196,8 +238,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--utts", type=int, default=UTTS_PER_GPU, help="utterances per GPU (default: the config-3 size)")
+    ap.add_argument("--utts", type=int, default=UTTS_PER_GPU,
+                    help="utterances per GPU (weak scaling) or in the whole corpus (strong scaling); default: the config-3 size")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --utts clips per GPU; strong: one corpus of --utts clips sharded over the GPUs "
+                         "(the shape BASELINE config 3 is quoted on)")
+    ap.add_argument("--comm", choices=("torch", "capi"), default="torch",
+                    help="collectives through torch.distributed (default) or through the library's own RCCL entry points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host -> device pipeline measurement")
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     args = ap.parse_args()
     if args.config != 3:
@@ -205,16 +254,24 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    workers = max(1, POOL // max(1, min(world, 8))) if world > 1 else POOL
+    workers = max(1, host_workers() // max(1, min(world, 8)))
+
+    from loe_speech_recognition_amd.distributed import shard_bounds
 
     # host-side work that forks happens before this process touches the GPU
-    sigs, truth = generate(rank, args.utts, workers)
+    if args.scaling == "strong":
+        n_total = args.utts
+        lo, hi = shard_bounds(n_total, rank, world)
+    else:
+        n_total = world * args.utts
+        lo, hi = rank * args.utts, (rank + 1) * args.utts
+    sigs, truth = generate(lo, hi - lo, workers)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, cpu_decoded, cpu_labeled = cpu_baseline(sigs[:CPU_SAMPLE], truth[:CPU_SAMPLE], POOL)
+        cpu, cpu_decoded = cpu_baseline(sigs, truth, workers)
 
     from loe_speech_recognition_amd import HiddenMarkovModelInference, _native
+    from loe_speech_recognition_amd.distributed import gather_label_records, records_to_strings
 
     torch, dist, eng, rank, world, backend = _setup(args)
     _native._engine, _native._engine_pid = eng, os.getpid()
@@ -222,63 +279,112 @@ def main():
     inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
     inf._log_transition_probability_between_words = BETWEEN
     inf._bind()
+    names = inf._model_boundaries._labels
+    comm = None
+    if world > 1 and args.comm == "capi":
+        from loe_speech_recognition_amd.distributed import NativeComm
+        comm = NativeComm.from_torch_group(eng)
 
     t0 = time.perf_counter()
     ab = eng.audio_batch(sigs)
     torch.cuda.synchronize()
     upload_s = time.perf_counter() - t0
     label_cap = 16
-    out = (eng.empty((ab.n,), torch.float32), None, eng.empty((ab.n, label_cap), torch.uint8),
-           eng.empty((ab.n,), torch.int32))
-    from loe_speech_recognition_amd.distributed import gather_label_records
-    state = {}
 
-    def step():
-        eng.recognize(ab, want_paths=False, label_cap=label_cap, out=out)
-        if world > 1:
-            # the exchange step of the path: every rank ends up with the label records (word ids + count)
-            # of the whole job, one all-gather of 20-byte records per step
-            if backend == "nccl":
-                state["records"] = gather_label_records(out[2], out[3], world * ab.n)
-            else:                                    # gloo rehearsal: records travel through host memory
-                state["records"] = gather_label_records(out[2].cpu(), out[3].cpu(), world * ab.n)
+    def make_step(batch, n_global):
+        out = (eng.empty((batch.n,), torch.float32), None, eng.empty((batch.n, label_cap), torch.uint8),
+               eng.empty((batch.n,), torch.int32))
+        state = {"out": out}
+
+        def step():
+            eng.recognize(batch, want_paths=False, label_cap=label_cap, out=out)
+            if world > 1:
+                # the exchange step of the path: every rank ends up with the label records (word ids + count)
+                # of the whole job in global utterance order, one all-gather of 20-byte records per step
+                if comm is not None:
+                    state["records"] = comm.gather_label_records(out[2], out[3], n_global)
+                elif backend == "nccl":
+                    state["records"] = gather_label_records(out[2], out[3], n_global)
+                else:                                    # gloo rehearsal: records travel through host memory
+                    state["records"] = gather_label_records(out[2].cpu(), out[3].cpu(), n_global)
+        return step, state
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    eng.profile_reset()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    eng.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def timed(step, steps, warmup, profile=False):
+        for _ in range(warmup):
+            step()
+        barrier()
+        if profile:
+            eng.profile_reset()
+            eng.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if profile:
+            eng.profile_enable(False)
+        return max_over_ranks(elapsed)
+
+    step, state = make_step(ab, n_total)
+    elapsed = timed(step, args.steps, args.warmup, profile=True)
+    out = state["out"]
 
     # results of the last step: strings, accuracy vs the generating strings and vs the CPU path
-    names = inf._model_boundaries._labels
-    lab = out[2].cpu().numpy()
-    cnt = out[3].cpu().numpy()
-    strings = ["".join(names[w] for w in lab[i, :min(int(cnt[i]), label_cap)]) for i in range(ab.n)]
+    strings = records_to_strings(out[2].cpu().numpy(), out[3].cpu().numpy(), names)
     n_right = sum(a == b for a, b in zip(strings, truth))
     if world > 1:
         t = torch.tensor([n_right], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n_right = float(t.item())
         g_lab, g_cnt = state["records"]
-        assert g_lab.shape[0] == world * ab.n and g_cnt.shape[0] == world * ab.n
-        lo = rank * ab.n                             # this rank's slice of the gathered records is its own output
-        assert torch.equal(g_lab[lo:lo + ab.n].cpu()[:, :1], out[2].cpu()[:, :1]) and torch.equal(g_cnt[lo:lo + ab.n].cpu(), out[3].cpu())
-    acc_truth = float(n_right) / (world * ab.n)
+        assert g_lab.shape[0] == n_total and g_cnt.shape[0] == n_total
+        # this rank's slice of the gathered records is its own output
+        assert records_to_strings(g_lab[lo:hi].cpu().numpy(), g_cnt[lo:hi].cpu().numpy(), names) == strings
+    acc_truth = float(n_right) / n_total
+
+    # strong-scaling shape of config 3 next to a weak-scaling run: ONE corpus of --utts clips sharded over the
+    # ranks (each rank decodes the first 1/world of its clips), same timing contract
+    strong = None
+    if world > 1 and args.scaling == "weak":
+        s_lo, s_hi = shard_bounds(args.utts, rank, world)
+        sub = eng.audio_batch(sigs[:s_hi - s_lo])
+        s_step, _ = make_step(sub, args.utts)
+        s_elapsed = timed(s_step, args.steps, max(2, args.warmup // 2))
+        strong = {"utterances_total": args.utts, "ms_per_step": s_elapsed / args.steps * 1e3,
+                  "value": args.utts * args.steps / s_elapsed, "unit": "utterances/s", "scaling": "strong"}
+
+    # the path as a caller with host arrays sees it: chunked, pinned, overlapped upload (lsr_recognize_host)
+    h2d = None
+    if world == 1 and not args.no_h2d:
+        h2d = {"pageable_synchronous_upload_s": round(upload_s, 4)}
+        h_steps = max(3, min(args.steps, 5))
+        for tag, clips in (("float32", sigs), ("int16", [np.round(c).astype(np.int16) for c in sigs])):
+            nbytes = float(sum(c.nbytes for c in clips))
+            for _ in range(2):
+                got = eng.recognize_host(clips, label_cap=label_cap, threads=workers)
+            t0 = time.perf_counter()
+            for _ in range(h_steps):
+                got = eng.recognize_host(clips, label_cap=label_cap, threads=workers)
+            dt = (time.perf_counter() - t0) / h_steps
+            h_strings = records_to_strings(got[1], got[2], names)
+            h2d[tag] = {"ms_per_step": dt * 1e3, "utterances_per_s": len(clips) / dt, "host_to_device_GBps": nbytes / dt / 1e9,
+                        "audio_mb": round(nbytes / 1e6, 1), "host_phases_last_call": eng.recognize_host_timing(),
+                        "strings_equal_to_resident_float32_path": sum(a == b for a, b in zip(h_strings, strings)) / len(clips)}
+        h2d["note"] = ("host clips (separate NumPy arrays) -> pinned staging by worker threads -> asynchronous copies "
+                       "overlapped with the decoding of earlier chunks -> host label records; int16 = the same clips "
+                       "rounded to 16-bit PCM as a wav file holds them")
 
     if rank == 0:
         kernels = {}
@@ -286,54 +392,78 @@ def main():
             ms, n = eng.profile_get(k)
             kernels[k] = {"ms_per_launch": ms / max(n, 1), "launches": n}
         total_frames = ab.total_frames
+        total_samples = float(ab.n_samples.sum())
         S = 58
-        flops = float(S) * total_frames * (2 * D * D + 3 * D)        # algorithmic flops of one emission launch
+        n_tiles = (total_frames + 63) // 64
         em_s = kernels["emission"]["ms_per_launch"] * 1e-3
-        achieved = flops / em_s / 1e12
+        # Executed flops of one emission launch: the kernel evaluates the Mahalanobis form through a lower-triangular
+        # factor in 4 x 4 blocks, 55 blocks x 4 frame groups = 220 MFMAs of 512 flop per (64 frames, state).  The dense
+        # definition (2*39^2 + 3*39 flop per (frame, state), what SciPy executes) counts 1.8x more than is executed and
+        # is reported beside it, not as the roofline fraction.
+        flops_exec = 220 * 512.0 * S * n_tiles
+        flops_dense = float(S) * total_frames * (2 * D * D + 3 * D)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "emission_traffic.json")
-        if os.path.exists(tpath) and args.utts == UTTS_PER_GPU:
+        if os.path.exists(tpath) and ab.n == UTTS_PER_GPU:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+
+        def hbm(bytes_alg, ms):
+            gbps = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"algorithmic_bytes": bytes_alg, "ms": ms, "GBps": gbps, "frac_of_peak": gbps / HBM_PEAK_GBPS}
+
+        step_ms = elapsed / args.steps * 1e3
         line = {
             "metric": "utterances/sec (whole node), 4-digit connected-digit decode (MFCC + 58-state loop Viterbi)",
-            "value": world * ab.n * args.steps / elapsed,
+            "value": n_total * args.steps / elapsed,
             "unit": "utterances/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"config 3: {ab.n} synthetic four-digit 16 kHz clips per GPU, S=58 loop decode, between=-100",
+            "config": {"workload": f"config 3: {n_total} synthetic four-digit 16 kHz clips ({ab.n} on this GPU), S=58 loop decode, "
+                                   f"between=-100, {args.scaling} scaling",
                        "utterances_per_gpu": ab.n, "frames_per_gpu": int(total_frames),
-                       "audio_mb_per_gpu": round(float(ab.n_samples.sum()) * 4 / 1e6, 1),
+                       "audio_mb_per_gpu": round(total_samples * 4 / 1e6, 1),
                        "parallelism": f"utterance-sharded x{world}" + (", all-gather of label records" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": "lsr_emission_kernel", "achieved": achieved,
-                         "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
-                         "traffic": traffic, "flops_per_launch": flops, "ms_per_launch": em_s * 1e3,
-                         # the kernel evaluates the same quadratic form through a triangular factor in 4 x 4 blocks:
-                         # 220 MFMAs of 512 flop per (64 frames, state) are issued, fewer than the dense definition counts
-                         "executed_tflops": 220 * 512.0 * S * ((total_frames + 63) // 64) / em_s / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "lsr_emission_kernel", "achieved": flops_exec / em_s / 1e12,
+                         "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops_exec / em_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                         "traffic": traffic, "flops_per_launch": flops_exec, "ms_per_launch": em_s * 1e3,
+                         "definition": "executed MFMA flops (triangular whitening factor in 4x4 blocks: 220 MFMA x 512 flop "
+                                       "per 64 frames x state) / HIP-event kernel time / FP64 matrix peak",
+                         "achieved_dense_equiv": flops_dense / em_s / 1e12, "flops_per_launch_dense_definition": flops_dense},
+            # algorithmic bytes / kernel time against the 8 TB/s HBM peak: the front-end kernels (HBM-bound by bytes) and
+            # the whole path (4 B audio in per sample + 16 B label record + 4 B score out per utterance)
+            "hbm": {"mel_power": hbm(4.0 * total_samples + 160.0 * total_frames, kernels["mel_power"]["ms_per_launch"]),
+                    "mfcc_finish": hbm(316.0 * total_frames, kernels["mfcc_finish"]["ms_per_launch"]),
+                    "whole_path": hbm(4.0 * total_samples + 20.0 * ab.n, step_ms)},
             "kernels_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in kernels.items()},
             "seq_accuracy_vs_truth": acc_truth,
-            "h2d_upload_s": round(upload_s, 4),
-            "value_including_h2d": world * ab.n / (elapsed / args.steps + upload_s),
         }
+        if strong is not None:
+            line["strong_scaling"] = strong
+        if h2d is not None:
+            line["h2d"] = h2d
+            line["value_including_h2d"] = h2d["float32"]["utterances_per_s"]
+            line["value_including_h2d_int16"] = h2d["int16"]["utterances_per_s"]
         if cpu is not None:
             # strings of the CPU sample, matched by position within each label group
             seen = {}
             agree = 0
-            for i in range(CPU_SAMPLE):
+            for i in range(cpu["n_utterances"]):
                 k = seen.get(truth[i], 0)
                 seen[truth[i]] = k + 1
                 agree += strings[i] == cpu_decoded[truth[i]][k]
-            line["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}
-            line["cpu_baseline"]["per_core_utterances_per_s"] = cpu["per_core"]
-            line["strings_equal_to_cpu_path"] = f"{agree}/{CPU_SAMPLE}"
+            line["cpu_baseline"] = cpu
+            line["strings_equal_to_cpu_path"] = f"{agree}/{cpu['n_utterances']}"
         print(json.dumps(line))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

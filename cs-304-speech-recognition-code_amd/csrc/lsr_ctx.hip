@@ -259,6 +259,7 @@ extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
     if (!ctx) return LSR_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    lsr_pipeline_destroy(ctx);
     lsr_frontend_free(ctx);
     free_ptr(ctx->d_wfrag);
     free_ptr(ctx->d_lognorm);
@@ -516,6 +517,17 @@ extern "C" int lsr_decode_loop_sweep(lsr_ctx* ctx, const float* feats_d, const i
     ctx->between = saved;
     ctx->between_is_f64 = saved_wide;
     return rc;
+}
+
+int lsr_reserve_recognize(lsr_ctx* ctx, int n_utts, int64_t total_frames) {
+    int rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_frame_utt, (size_t)total_frames * sizeof(int32_t), "frame index"))) return rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_mel, (size_t)total_frames * LSR_N_MELS * sizeof(float), "mel energies"))) return rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_uttmax, (size_t)n_utts * sizeof(unsigned int), "utterance maxima"))) return rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_frame_info, (size_t)total_frames * 16, "frame records"))) return rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_feats, (size_t)total_frames * LSR_DIM * sizeof(float), "features"))) return rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(total_frames), "emission scores"))) return rc;
+    return lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * 64, "back-pointers");
 }
 
 static int recognize_any(lsr_ctx* ctx, const void* audio_d, int is_i16, const int64_t* sample_off_d,

@@ -55,6 +55,9 @@ struct lsr_ctx {
     // workspace
     lsr_buffer ws_frame_utt, ws_mel, ws_uttmax, ws_feats, ws_ll, ws_tracer, ws_slab, ws_sep, ws_frame_info, ws_sort;
 
+    // host -> device pipeline of lsr_recognize_host (created on first use)
+    struct lsr_pipeline* pipeline = nullptr;
+
     // profiling
     bool profiling = false;
     struct pending { int kernel; hipEvent_t start, stop; };
@@ -70,6 +73,9 @@ void lsr_prof_begin(lsr_ctx* ctx, int kernel);
 void lsr_prof_end(lsr_ctx* ctx);
 int lsr_frontend_init(lsr_ctx* ctx);
 void lsr_frontend_free(lsr_ctx* ctx);
+// grows every workspace buffer of the audio -> labels path to a batch of n_utts utterances / total_frames frames
+int lsr_reserve_recognize(lsr_ctx* ctx, int n_utts, int64_t total_frames);
+void lsr_pipeline_destroy(lsr_ctx* ctx);
 int lsr_noalloc_init(lsr_ctx* ctx);      // resolves the device address of the static workspace (once per device)
 
 #define LSR_HIP_CHECK(ctx, expr)                                                              \

@@ -59,6 +59,8 @@ def _declare(lib) -> None:
         "lsr_mfcc_batch_i16": (c_int, [P, P, P, P, c_int, c_int64, P]),
         "lsr_recognize_batch_i16": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_recognize_batch_noalloc": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
+        "lsr_recognize_host": (c_int, [P, P, P, c_int, c_int, c_int64, c_int, P, P, P, c_int]),
+        "lsr_recognize_host_timing": (c_int, [P, POINTER(c_double), POINTER(c_int)]),
         "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
         "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_decode_loop_sweep": (c_int, [P, P, P, c_int, c_int64, c_int, POINTER(c_double), POINTER(c_int32), c_int,
@@ -85,6 +87,7 @@ EXPORTED_SYMBOLS = [
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
     "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures", "lsr_separation_scan",
     "lsr_gather_segments", "lsr_decode_loop_sweep", "lsr_recognize_batch_noalloc",
+    "lsr_recognize_host", "lsr_recognize_host_timing",
 ]
 
 
@@ -339,6 +342,46 @@ class Engine:
                                                  self._ptr(scores), self._ptr(paths), self._ptr(labels),
                                                  self._ptr(n_labels), label_cap))
         return out
+
+    def recognize_host(self, signals: Sequence[np.ndarray], label_cap: int = 32, chunk_samples: int = 0,
+                       threads: int = 0):
+        """Host clips in, host results out through the chunked upload pipeline (lsr_recognize_host):
+        (scores f32[B], labels u8[B, cap], n_labels i32[B]) as NumPy arrays.  ``signals`` are 1-D
+        int16 arrays (all of them) or anything convertible to float32; no concatenation happens here,
+        the library packs straight from the arrays into pinned staging memory."""
+        if len(signals) == 0:
+            raise ValueError("empty batch")
+        from . import _lsr_pyhelper as H          # built by the Makefile next to this file
+
+        clips = signals if isinstance(signals, list) else list(signals)
+        ptrs = np.empty(len(clips), np.uint64)
+        n = np.empty(len(clips), np.int64)
+        kind = H.clip_table(clips, ptrs, n)
+        if kind < 0:                              # mixed types, views, other dtypes: convert like audio_batch does
+            is_i16 = all(isinstance(s, np.ndarray) and s.dtype == np.int16 for s in clips)
+            clips = [np.ascontiguousarray(s, dtype=np.int16 if is_i16 else np.float32) for s in clips]
+            kind = H.clip_table(clips, ptrs, n)
+            if kind < 0:
+                raise ValueError("clips must be 1-D arrays")
+        is_i16 = kind == H.INT16
+        if (1 + n // HOP).min() < MIN_FRAMES:
+            raise ValueError(f"a clip yields {int((1 + n // HOP).min())} frames; the width-9 delta filter needs at least {MIN_FRAMES}")
+        B = len(clips)
+        scores = np.empty(B, np.float32)
+        labels = np.empty((B, label_cap), np.uint8)
+        n_labels = np.empty(B, np.int32)
+        self._check(self.lib.lsr_recognize_host(self.ctx, c_void_p(ptrs.ctypes.data), c_void_p(n.ctypes.data), B,
+                                                1 if is_i16 else 0, int(chunk_samples), int(threads),
+                                                c_void_p(scores.ctypes.data), c_void_p(labels.ctypes.data),
+                                                c_void_p(n_labels.ctypes.data), label_cap))
+        return scores, labels, n_labels
+
+    def recognize_host_timing(self) -> dict:
+        """Host seconds of the last recognize_host call by phase (diagnostic)."""
+        t = (c_double * 4)()
+        n = c_int(0)
+        self._check(self.lib.lsr_recognize_host_timing(self.ctx, t, ctypes.byref(n)))
+        return {"wait_slot_s": t[0], "pack_s": t[1], "submit_s": t[2], "drain_s": t[3], "chunks": n.value}
 
     def recognize_noalloc(self, ab: AudioBatch, out):
         """lsr_recognize_batch_noalloc into caller-provided outputs (scores, paths or None, labels, n_labels):

@@ -509,16 +509,25 @@ class HiddenMarkovModelInference:
             out.append(row)
         return out
 
-    def recognize_audio(self, signals, label_cap: int = 32) -> List[str]:
+    def recognize_audio(self, signals, label_cap: int = 32, streamed: bool = False, chunk_samples: int = 0,
+                        threads: int = 0) -> List[str]:
         """Audio in, label strings out: MFCC + decode without the features leaving the device
-        (the per-utterance work of scripts/project5_test_ndigits_with_sil.py:64-77)."""
+        (the per-utterance work of scripts/project5_test_ndigits_with_sil.py:64-77).
+        ``streamed=True`` takes host arrays (int16 as read from a wav file, or float32) through the
+        chunked upload pipeline: pinned staging, asynchronous copies overlapped with the decoding of
+        earlier chunks; the strings are the same as with one resident batch."""
         eng = self._bind()
+        names = self._model_boundaries._labels
+        if streamed and not isinstance(signals, _native.AudioBatch):
+            _, lab, cnt = eng.recognize_host(signals, label_cap=label_cap, chunk_samples=chunk_samples, threads=threads)
+            if (cnt > label_cap).any():
+                return self.recognize_audio(signals, label_cap=label_cap)
+            return ["".join(names[w] for w in lab[i, :int(cnt[i])]) for i in range(lab.shape[0])]
         ab = signals if isinstance(signals, _native.AudioBatch) else eng.audio_batch(signals)
         _, _, labels, n_labels = eng.recognize(ab, want_paths=False, label_cap=label_cap)
         cnt = n_labels.cpu().numpy()
         if (cnt > label_cap).any():
             return self.predict_batch(eng.mfcc(ab), label_cap=label_cap)
-        names = self._model_boundaries._labels
         lab = labels.cpu().numpy()
         return ["".join(names[w] for w in lab[i, :int(cnt[i])]) for i in range(ab.n)]
 

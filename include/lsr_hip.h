@@ -149,6 +149,27 @@ int lsr_recognize_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, const int64_t*
                             int max_frames, float* scores_d, int8_t* paths_d, uint8_t* labels_d,
                             int32_t* n_labels_d, int label_cap);
 
+/* The whole per-utterance flow of scripts/project5_test_ndigits_with_sil.py:64-77 starting from HOST
+ * arrays, as the reference's loader delivers them (ti_digits.py:130-134: wavfile.read -> int16, or
+ * its float32 conversion): clips[b] points to the n_samples[b] samples of clip b (int16 when
+ * audio_is_i16 != 0, else float32) anywhere in host memory - no concatenation is needed.  The clips
+ * are packed chunk by chunk (about chunk_samples samples each, <= 0: a default of 24 Mi samples)
+ * into pinned staging memory by n_threads worker threads (<= 0: 8), uploaded with asynchronous
+ * copies on a separate stream, and decoded (lsr_recognize_batch[_i16]) while later chunks are
+ * packed and uploaded; three staging slots rotate.  Outputs are HOST arrays, complete when the call
+ * returns: scores float32[B] (may be NULL), labels uint8[B][label_cap], n_labels int32[B], with the
+ * same contents lsr_recognize_batch produces for the whole batch at once.  Staging buffers are
+ * kept by the context and reused. */
+int lsr_recognize_host(lsr_ctx* ctx, const void* const* clips, const int64_t* n_samples, int n_utts,
+                       int audio_is_i16, int64_t chunk_samples, int n_threads, float* scores,
+                       uint8_t* labels, int32_t* n_labels, int label_cap);
+
+/* Host time of the last lsr_recognize_host call by phase: seconds4 = {waiting for a free staging slot,
+ * packing clips into pinned memory, submitting copies and kernels, waiting for the last chunk and
+ * copying the results back}; *n_chunks (may be NULL) = number of chunks.  A diagnostic for tuning
+ * chunk_samples / n_threads; no counterpart in the reference. */
+int lsr_recognize_host_timing(lsr_ctx* ctx, double* seconds4, int* n_chunks);
+
 /* lsr_recognize_batch (float32 audio) for callers that cannot allocate device memory: code under
  * HIP stream capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
  * in the reference.  Same arguments, same kernels and bit-identical outputs; every intermediate
