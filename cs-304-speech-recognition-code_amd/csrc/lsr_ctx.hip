@@ -260,6 +260,7 @@ extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     lsr_pipeline_destroy(ctx);
+    lsr_comm_destroy(ctx);
     lsr_frontend_free(ctx);
     free_ptr(ctx->d_wfrag);
     free_ptr(ctx->d_lognorm);

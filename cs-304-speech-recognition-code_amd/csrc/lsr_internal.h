@@ -58,6 +58,9 @@ struct lsr_ctx {
     // host -> device pipeline of lsr_recognize_host (created on first use)
     struct lsr_pipeline* pipeline = nullptr;
 
+    // RCCL communicator of lsr_comm_init (multi-GPU exchange steps)
+    struct lsr_comm* comm = nullptr;
+
     // profiling
     bool profiling = false;
     struct pending { int kernel; hipEvent_t start, stop; };

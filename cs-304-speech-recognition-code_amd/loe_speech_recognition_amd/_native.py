@@ -61,6 +61,17 @@ def _declare(lib) -> None:
         "lsr_recognize_batch_noalloc": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_recognize_host": (c_int, [P, P, P, c_int, c_int, c_int64, c_int, P, P, P, c_int]),
         "lsr_recognize_host_timing": (c_int, [P, POINTER(c_double), POINTER(c_int)]),
+        "lsr_shard_bounds": (None, [c_int64, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
+        "lsr_comm_get_unique_id": (c_int, [P, P]),
+        "lsr_comm_init": (c_int, [P, P, c_int, c_int]),
+        "lsr_comm_destroy": (c_int, [P]),
+        "lsr_allgather_labels": (c_int, [P, P, P, c_int64, c_int, c_int64, P, P]),
+        "lsr_allreduce_stats": (c_int, [P, P, c_int64]),
+        "lsr_label_record_bytes": (c_int64, [c_int]),
+        "lsr_host_pack_label_records": (c_int, [P, P, c_int64, c_int, c_int64, P]),
+        "lsr_host_unpack_label_records": (c_int, [P, c_int, c_int64, c_int64, c_int, P, P]),
+        "lsr_pack_label_records": (c_int, [P, P, P, c_int64, c_int, c_int64, P]),
+        "lsr_unpack_label_records": (c_int, [P, P, c_int, c_int64, c_int, P, P]),
         "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
         "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_decode_loop_sweep": (c_int, [P, P, P, c_int, c_int64, c_int, POINTER(c_double), POINTER(c_int32), c_int,
@@ -87,7 +98,9 @@ EXPORTED_SYMBOLS = [
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
     "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures", "lsr_separation_scan",
     "lsr_gather_segments", "lsr_decode_loop_sweep", "lsr_recognize_batch_noalloc",
-    "lsr_recognize_host", "lsr_recognize_host_timing",
+    "lsr_recognize_host", "lsr_recognize_host_timing", "lsr_shard_bounds", "lsr_comm_get_unique_id", "lsr_comm_init",
+    "lsr_comm_destroy", "lsr_allgather_labels", "lsr_allreduce_stats", "lsr_label_record_bytes",
+    "lsr_host_pack_label_records", "lsr_host_unpack_label_records", "lsr_pack_label_records", "lsr_unpack_label_records",
 ]
 
 

@@ -239,6 +239,48 @@ int lsr_remux_slots(lsr_ctx* ctx, const int8_t* paths_d, const int64_t* frame_of
                     const int32_t* chain_word_d, int n_utts, int64_t total_frames, int n_states,
                     int drop_last_run, int32_t* slots_d, int64_t* trans_d);
 
+/* ---- multi-GPU exchange steps (RCCL) ---------------------------------------------------------- */
+/* The reference fans work out to host processes and collects the results through pickled return
+ * values (scripts/project5_test_ndigits_with_sil.py:29-42 for decoding, hidden_markov_model.py:746-750
+ * for training).  Here every GPU has its own process and context; utterances are sharded in contiguous
+ * ranges and two collectives replace the collection step.  RCCL is loaded on first use (dlopen of
+ * librccl.so.1); nothing else in the library needs it. */
+#define LSR_COMM_ID_BYTES 128
+/* Contiguous shard [lo, hi) of `rank`: sizes differ by at most one, earlier ranks take the extra item. */
+void lsr_shard_bounds(int64_t n_items, int rank, int world, int64_t* lo, int64_t* hi);
+/* Rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ * (file, socket, MPI, torch.distributed); then every rank calls lsr_comm_init with its rank. */
+int lsr_comm_get_unique_id(lsr_ctx* ctx, void* id_out);
+int lsr_comm_init(lsr_ctx* ctx, const void* unique_id, int rank, int world);
+int lsr_comm_destroy(lsr_ctx* ctx);
+/* Decoded label records of the whole job on every rank, in global utterance order: labels_d
+ * uint8[n_local][label_cap] / n_labels_d int32[n_local] are this rank's outputs of lsr_decode_loop_batch
+ * or lsr_recognize_batch for its shard lsr_shard_bounds(n_total, rank, world); labels_out_d
+ * uint8[n_total][label_cap] and n_labels_out_d int32[n_total] receive all of them.  One ncclAllGather
+ * of fixed-width records on the context's stream (asynchronous like the kernels). */
+int lsr_allgather_labels(lsr_ctx* ctx, const uint8_t* labels_d, const int32_t* n_labels_d, int64_t n_local,
+                         int label_cap, int64_t n_total, uint8_t* labels_out_d, int32_t* n_labels_out_d);
+/* In-place sum over all ranks of the packed float64 training statistics (counts, sum_x, sum_xx of
+ * lsr_accumulate_stats, transition counts converted to float64): one ncclAllReduce per training
+ * iteration, after which every rank runs the same M-step (hidden_markov_model.py:754-770). */
+int lsr_allreduce_stats(lsr_ctx* ctx, double* stats_d, int64_t count);
+/* The record layout of lsr_allgather_labels on the host (no GPU needed; also used by CPU-side
+ * transports): a record is label_cap label bytes followed by the little-endian int32 count
+ * (lsr_label_record_bytes); a rank contributes shard_cap = size of the largest shard records, unused
+ * ones filled with 0xFF; unpack reads world * shard_cap records back into global order. */
+int64_t lsr_label_record_bytes(int label_cap);
+int lsr_host_pack_label_records(const uint8_t* labels, const int32_t* n_labels, int64_t n_local, int label_cap,
+                                int64_t shard_cap, uint8_t* records);
+int lsr_host_unpack_label_records(const uint8_t* records, int world, int64_t shard_cap, int64_t n_total,
+                                  int label_cap, uint8_t* labels, int32_t* n_labels);
+/* The same two steps on the device (context's stream), for callers that bring their own all-gather
+ * (MPI, torch.distributed): records_d holds shard_cap records (pack) / world * shard_cap records with
+ * shard_cap = size of shard 0 of n_total (unpack). */
+int lsr_pack_label_records(lsr_ctx* ctx, const uint8_t* labels_d, const int32_t* n_labels_d, int64_t n_local,
+                           int label_cap, int64_t shard_cap, uint8_t* records_d);
+int lsr_unpack_label_records(lsr_ctx* ctx, const uint8_t* records_d, int world, int64_t n_total, int label_cap,
+                             uint8_t* labels_out_d, int32_t* n_labels_out_d);
+
 /* ---- silence stripping ------------------------------------------------------------------- */
 /* Replaces the per-clip scan of SignalSeparation._remove_empty / .detect_speech
  * (signal_separation.py:102-164) for a batch of clips.  A clip of N samples has

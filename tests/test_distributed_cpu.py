@@ -66,6 +66,14 @@ def _worker(rank, world, port, out_dir):
     lo, hi = D.shard_bounds(11, rank, world)
     g_lab, g_n = D.gather_label_records(torch.from_numpy(lab[lo:hi]), torch.from_numpy(n[lo:hi]), 11)
     assert np.array_equal(g_lab.numpy(), lab) and np.array_equal(g_n.numpy(), n)
+    # the strings every rank reads from the gathered records are the single-rank strings
+    names = list("123456789OSZ")
+    assert D.records_to_strings(g_lab.numpy(), g_n.numpy(), names) == D.records_to_strings(lab, n, names)
+    # strong-scaling shape: one corpus of 10 utterances sharded 5 + 5, and an uneven 3-way split seen from 2 ranks' shards
+    lab10, n10 = _fake_records(10, seed=5)
+    lo, hi = D.shard_bounds(10, rank, world)
+    g_lab, g_n = D.gather_label_records(torch.from_numpy(lab10[lo:hi]), torch.from_numpy(n10[lo:hi]), 10)
+    assert D.records_to_strings(g_lab.numpy(), g_n.numpy(), names) == D.records_to_strings(lab10, n10, names)
     # statistics: each rank reduces its half of the frames (cut at a state-run boundary is not required)
     frames, state = _aligned_data()
     lo, hi = D.shard_bounds(400, rank, world)
@@ -111,3 +119,34 @@ def test_shard_bounds_cover_everything():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert D.records_to_strings(np.array([[1, 2, 3]], np.uint8), np.array([2], np.int32), list("0123")) == ["12"]
+
+
+@pytest.mark.parametrize("n_total,world", [(11, 2), (10, 2), (7, 3), (3, 8), (1, 1), (10000, 8), (10001, 4)])
+def test_record_layout_round_trip(n_total, world):
+    """lsr_host_pack_label_records per rank, concatenated as an all-gather would, then
+    lsr_host_unpack_label_records: the original records in global order; lsr_shard_bounds is the Python rule."""
+    import ctypes
+
+    from loe_speech_recognition_amd import _native
+    from loe_speech_recognition_amd import distributed as D
+
+    lib = _native.load_library()
+    cap = 6
+    lab, n = _fake_records(n_total, cap=cap, seed=n_total + world)
+    n[0] = -1 if n_total > 1 else n[0]                     # counts travel as raw int32
+    shard_cap = D.shard_bounds(n_total, 0, world)[1]
+    pieces = []
+    for r in range(world):
+        lo, hi = D.shard_bounds(n_total, r, world)
+        c_lo, c_hi = ctypes.c_int64(-1), ctypes.c_int64(-1)
+        lib.lsr_shard_bounds(n_total, r, world, ctypes.byref(c_lo), ctypes.byref(c_hi))
+        assert (c_lo.value, c_hi.value) == (lo, hi)
+        piece = D.pack_label_records(lab[lo:hi], n[lo:hi], shard_cap)
+        assert piece.shape == (shard_cap, cap + 4) and (piece[hi - lo:] == 0xFF).all()
+        if hi > lo:
+            assert np.array_equal(piece[0, :cap], lab[lo]) and piece[0, cap:].view(np.int32)[0] == n[lo]
+        pieces.append(piece)
+    g_lab, g_n = D.unpack_label_records(np.concatenate(pieces), world, n_total, cap)
+    assert np.array_equal(g_lab, lab) and np.array_equal(g_n, n)
+    with pytest.raises(ValueError):
+        D.pack_label_records(lab, n, max(0, n_total - 1))
