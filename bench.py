@@ -192,8 +192,8 @@ def other_config(args):
         for lab in synthetic.WORDS + ["S"]:
             tc.add_model(models[lab])
         fb = eng.mfcc(ab)
-        labeled = {"__prepared__": None}
-        tc.__dict__["_data_cache"] = {"key": id(labeled), "fb": fb, "owner": truth}
+        labeled = None
+        tc.use_device_batch(fb, truth)
 
         def step():
             tc._iteration(labeled)

@@ -97,13 +97,14 @@ __global__ __launch_bounds__(64) void lsr_sep_scan_kernel(const float* __restric
     const int64_t lo = scan_off[b], hi = scan_off[b + 1];
     float mx = 0.0f;
     for (int64_t k = lo; k < hi; ++k) mx = fmaxf(mx, fmax[k]);
-    // threshold * max_volume is a Python float; NumPy compares the float32 energy against its float32 rounding
-    const float thr_high = (float)(high * (double)mx);
-    const float thr_low = (float)(low * (double)mx);
+    // threshold * max_volume is an np.float64 (the maximum is converted with .astype(float)), so NumPy promotes
+    // the float32 energy and compares in float64; NaN (the empty trailing frame) compares false either way
+    const double thr_high = high * (double)mx;
+    const double thr_low = low * (double)mx;
     bool between = false, ever = false;
     int counter = 0, first = -1, end = -1;
     for (int64_t k = lo; k < hi; ++k) {
-        const float e = energy[k];
+        const double e = (double)energy[k];
         bool tripped = false;
         if (between) {
             if (e > thr_low) {

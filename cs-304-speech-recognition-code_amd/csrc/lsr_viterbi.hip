@@ -139,6 +139,42 @@ __device__ __forceinline__ float vit_step(const vit_args& A, float prev, float e
     return cur;
 }
 
+// ModelBoundary.get_labels for one utterance, evaluated by the 64 lanes of a wavefront: the rule is local
+// (a word is emitted at frame 0, where the word changes, and where the path jumps from a word's last
+// state back to its first), so every lane tests its own frame and the emitted words are compacted with
+// ballot / popcount into the fixed-width record.  States outside the graph (-1: no back-pointer) emit nothing.
+__device__ __forceinline__ void vit_labels(const vit_args& A, const int8_t* __restrict__ path, int T, int b, int lane) {
+    int count = 0;
+    for (int base = 0; base < T; base += 64) {
+        const int t = base + lane;
+        bool emit = false;
+        int w = 0;
+        if (t < T) {
+            const int p = path[t];
+            if (p >= 0 && p < A.n_states) {
+                w = A.word_of[p];
+                if (t == 0) {
+                    emit = true;
+                } else {
+                    const int q = path[t - 1];
+                    if (q >= 0 && q < A.n_states && p != q) {
+                        const int wq = A.word_of[q];
+                        emit = (w != wq) || (q == A.upper_of[q] && p == A.lower_of[q]);
+                    }
+                }
+                if (w == A.silence) emit = false;
+            }
+        }
+        const unsigned long long mask = __ballot(emit);
+        if (emit && A.labels) {
+            const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < A.label_cap) A.labels[(int64_t)b * A.label_cap + pos] = (uint8_t)w;
+        }
+        count += __popcll(mask);
+    }
+    if (A.n_labels && lane == 0) A.n_labels[b] = count;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,6 +186,21 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
     const int64_t off = A.frame_off[b];
     const int T = (int)(A.frame_off[b + 1] - off);
     if (T < 1) return;
+    // Sizes the host promised but the device tables contradict (an utterance longer than max_frames would
+    // overrun the LDS path buffer; a chain outside 1..64 states has no lane mapping): the utterance gets
+    // the sentinels score = NaN and n_labels = -1 and nothing else is written for it.
+    bool bad = T > A.path_cap;
+    if (MODE == VIT_CHAIN) {
+        const int64_t len = A.chain_off[b + 1] - A.chain_off[b];
+        bad = bad || len < 1 || len > 64;
+    }
+    if (bad) {
+        if (lane == 0) {
+            if (A.scores) A.scores[b] = __builtin_nanf("");
+            if (A.n_labels) A.n_labels[b] = -1;
+        }
+        return;
+    }
 
     // ---- per-lane graph constants -------------------------------------------------------------
     int n, gid;
@@ -157,8 +208,7 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
     bool is_start, is_entry = false, is_exit = false;
     if (MODE == VIT_CHAIN) {
         const int64_t c0 = A.chain_off[b];
-        int len = (int)(A.chain_off[b + 1] - c0);
-        n = len > 64 ? 64 : len;
+        n = (int)(A.chain_off[b + 1] - c0);
         const bool live = lane < n;
         const int64_t i = c0 + (live ? lane : 0);
         gid = live ? A.chain_state[i] : 0;
@@ -261,40 +311,22 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
         for (int t = lane; t < T; t += 64) A.paths[off + t] = pathbuf[t];
 
     // ---- path -> word labels (loop graph only) ---------------------------------------------------
-    if (MODE != VIT_CHAIN && (A.labels || A.n_labels)) {
-        int count = 0;
-        for (int base = 0; base < T; base += 64) {
-            const int t = base + lane;
-            bool emit = false;
-            int w = 0;
-            if (t < T) {
-                const int p = pathbuf[t];
-                if (p >= 0) {
-                    w = A.word_of[p];
-                    if (t == 0) {
-                        emit = true;
-                    } else {
-                        const int q = pathbuf[t - 1];
-                        if (q >= 0 && p != q) {
-                            const int wq = A.word_of[q];
-                            emit = (w != wq) || (q == A.upper_of[q] && p == A.lower_of[q]);
-                        }
-                    }
-                    if (w == A.silence) emit = false;
-                }
-            }
-            const unsigned long long mask = __ballot(emit);
-            if (emit && A.labels) {
-                const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < A.label_cap) A.labels[(int64_t)b * A.label_cap + pos] = (uint8_t)w;
-            }
-            count += __popcll(mask);
-        }
-        if (A.n_labels && lane == 0) A.n_labels[b] = count;
-    }
+    if (MODE != VIT_CHAIN && (A.labels || A.n_labels)) vit_labels(A, pathbuf, T, b, lane);
 }
 
-// tracer_d: back-pointer table int8[total_frames][64] supplied by the caller, or NULL to use the context's workspace
+// The label pass on its own: paths in, label records out (one wavefront per utterance, the path is read
+// from memory instead of the decoder's LDS copy).
+__global__ __launch_bounds__(64) void lsr_path_labels_kernel(vit_args A) {
+    const int b = blockIdx.x;
+    const int64_t off = A.frame_off[b];
+    const int T = (int)(A.frame_off[b + 1] - off);
+    if (T < 1) {
+        if (A.n_labels && threadIdx.x == 0) A.n_labels[b] = 0;
+        return;
+    }
+    vit_labels(A, A.paths + off, T, b, threadIdx.x);
+}
+
 static int launch(lsr_ctx* ctx, int mode, vit_args& A, int n_utts, int64_t total_frames, int max_frames,
                   int8_t* tracer_d = nullptr) {
     if (!tracer_d) {
@@ -359,4 +391,27 @@ int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* fra
     A.paths = paths_d;
     A.final_ll = final_d;
     return launch(ctx, VIT_CHAIN, A, n_utts, total_frames, max_frames);
+}
+
+extern "C" int lsr_labels_from_paths(lsr_ctx* ctx, const int8_t* paths_d, const int64_t* frame_off_d, int n_utts,
+                                     uint8_t* labels_d, int32_t* n_labels_d, int label_cap) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!paths_d || !frame_off_d || !n_labels_d || n_utts < 1) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_labels_from_paths: bad argument");
+    if (labels_d && label_cap < 1) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_labels_from_paths: label_cap < 1");
+    if (ctx->g_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_labels_from_paths: no loop graph uploaded");
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    vit_args A = {};
+    A.frame_off = frame_off_d;
+    A.word_of = ctx->d_word_of;
+    A.lower_of = ctx->d_lower_of;
+    A.upper_of = ctx->d_upper_of;
+    A.n_states = ctx->g_states;
+    A.silence = ctx->g_silence;
+    A.paths = const_cast<int8_t*>(paths_d);
+    A.labels = labels_d;
+    A.n_labels = n_labels_d;
+    A.label_cap = label_cap;
+    hipLaunchKernelGGL(lsr_path_labels_kernel, dim3((unsigned)n_utts), dim3(64), 0, ctx->stream, A);
+    LSR_LAUNCH_CHECK(ctx, "lsr_path_labels_kernel");
+    return LSR_OK;
 }

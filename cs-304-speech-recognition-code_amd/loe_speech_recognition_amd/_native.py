@@ -72,6 +72,7 @@ def _declare(lib) -> None:
         "lsr_host_unpack_label_records": (c_int, [P, c_int, c_int64, c_int64, c_int, P, P]),
         "lsr_pack_label_records": (c_int, [P, P, P, c_int64, c_int, c_int64, P]),
         "lsr_unpack_label_records": (c_int, [P, P, c_int, c_int64, c_int, P, P]),
+        "lsr_labels_from_paths": (c_int, [P, P, P, c_int, P, P, c_int]),
         "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
         "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_decode_loop_sweep": (c_int, [P, P, P, c_int, c_int64, c_int, POINTER(c_double), POINTER(c_int32), c_int,
@@ -101,6 +102,7 @@ EXPORTED_SYMBOLS = [
     "lsr_recognize_host", "lsr_recognize_host_timing", "lsr_shard_bounds", "lsr_comm_get_unique_id", "lsr_comm_init",
     "lsr_comm_destroy", "lsr_allgather_labels", "lsr_allreduce_stats", "lsr_label_record_bytes",
     "lsr_host_pack_label_records", "lsr_host_unpack_label_records", "lsr_pack_label_records", "lsr_unpack_label_records",
+    "lsr_labels_from_paths",
 ]
 
 
@@ -168,13 +170,21 @@ class Engine:
     def __init__(self, device: Optional[int] = None):
         import torch
 
+        global _hip_pid
         self.torch = torch
         self.lib = load_library()
+        if _hip_pid is not None and _hip_pid != os.getpid():
+            # the HIP runtime does not survive fork(): its state in the child is a copy of the parent's
+            raise NativeError(
+                f"this process (pid {os.getpid()}) was forked from pid {_hip_pid} after that process had initialised the "
+                "GPU; HIP cannot be used in such a child.  Start workers with the 'spawn' method "
+                "(multiprocessing.get_context('spawn')) or fork them before the first GPU call.")
         if not torch.cuda.is_available():
             raise NativeError("no GPU visible: liblsr_hip needs an AMD GPU (there is no CPU fallback)")
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
         self.device_index = device
+        _hip_pid = os.getpid()
         torch.cuda.set_device(device)
         self.device = torch.device("cuda", device)
         ctx = c_void_p()
@@ -356,6 +366,19 @@ class Engine:
                                                  self._ptr(n_labels), label_cap))
         return out
 
+    def labels_from_paths(self, paths: Sequence[np.ndarray], label_cap: int = 32):
+        """Device label pass over given state paths (int8 arrays): (labels u8[B, cap], n_labels i32[B]) tensors."""
+        lengths = np.array([len(p) for p in paths], dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        flat = np.concatenate([np.asarray(p, dtype=np.int8) for p in paths])
+        d_paths, d_off = self.to_device(flat), self.to_device(off)
+        labels = self.empty((len(paths), label_cap), self.torch.uint8)
+        n_labels = self.empty((len(paths),), self.torch.int32)
+        self._check(self.lib.lsr_labels_from_paths(self.ctx, self._ptr(d_paths), self._ptr(d_off), len(paths),
+                                                   self._ptr(labels), self._ptr(n_labels), label_cap))
+        self.synchronize()
+        return labels, n_labels
+
     def recognize_host(self, signals: Sequence[np.ndarray], label_cap: int = 32, chunk_samples: int = 0,
                        threads: int = 0):
         """Host clips in, host results out through the chunked upload pipeline (lsr_recognize_host):
@@ -511,13 +534,15 @@ class Engine:
 
 _engine: Optional[Engine] = None
 _engine_pid: Optional[int] = None
+_hip_pid: Optional[int] = None          # pid of the process in which an Engine first touched the GPU
 
 
 def get_engine() -> Engine:
-    """Process-wide engine (created on first use; re-created in a forked/spawned child)."""
+    """Process-wide engine, created on first use.  A spawned worker, or one forked before any GPU call, creates
+    its own; a worker forked AFTER the parent used the GPU gets a NativeError (HIP does not survive fork)."""
     global _engine, _engine_pid
     if _engine is None or _engine_pid != os.getpid():
-        _engine = Engine()
+        _engine = Engine()                # raises in a child forked from a process that initialised the GPU
         _engine_pid = os.getpid()
     return _engine
 

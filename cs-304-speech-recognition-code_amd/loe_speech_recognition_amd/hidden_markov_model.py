@@ -638,19 +638,33 @@ class HiddenMarkovModelTrainContinuous:
             n += self._trainable_models[lab].num_of_states
         return base, n
 
-    def _prepare(self, labeled_mfccs: Dict[str, List[np.ndarray]]):
-        """Upload the utterances once; remember which label string each one carries."""
-        key = id(labeled_mfccs)
+    def _prepare(self, labeled_mfccs: Optional[Dict[str, List[np.ndarray]]]):
+        """Upload the utterances once; remember which label string each one carries.  The upload is reused
+        only for the very same dict holding the very same arrays (the cache keeps both alive, so an
+        address cannot be recycled by new data); ``None`` selects a batch installed with use_device_batch."""
         cache = self.__dict__.get("_data_cache")
-        if cache is None or cache["key"] != key:
+        if labeled_mfccs is None:
+            if cache is None or cache["src"] is not None:
+                raise ValueError("no device batch installed: call use_device_batch(features, label_strings) first")
+            return cache["fb"], cache["owner"]
+        finger = tuple((digits, len(seqs), tuple(map(id, seqs))) for digits, seqs in labeled_mfccs.items())
+        if cache is None or cache["src"] is not labeled_mfccs or cache["finger"] != finger:
             eng = _native.get_engine()
             utts, owner = [], []
             for digits, seqs in labeled_mfccs.items():
                 utts.extend(seqs)
                 owner.extend([digits] * len(seqs))
-            cache = {"key": key, "fb": eng.feature_batch(utts), "owner": owner}
+            cache = {"src": labeled_mfccs, "finger": finger, "keep": utts, "fb": eng.feature_batch(utts), "owner": owner}
             self.__dict__["_data_cache"] = cache
         return cache["fb"], cache["owner"]
+
+    def use_device_batch(self, fb: "_native.FeatureBatch", label_strings: Sequence[str]) -> None:
+        """Train on features that are already on the device (e.g. from MFCC.batch_device): utterance b of
+        ``fb`` carries the digit string ``label_strings[b]``.  Afterwards ``train(None)`` / ``_iteration(None)``
+        use this batch."""
+        if fb.n != len(label_strings):
+            raise ValueError("one label string per utterance")
+        self.__dict__["_data_cache"] = {"src": None, "finger": None, "keep": None, "fb": fb, "owner": list(label_strings)}
 
     def _chains(self, owner: List[str]):
         """Flat arrays describing the alignment chain S d S d ... S of every utterance

@@ -31,7 +31,11 @@ class ModelCollection:
     def _bind(self):
         eng = _native.get_engine()
         cache = self.__dict__.get("_dev_cache")
-        if cache is None or cache["n"] != len(self._models):
+        # the upload belongs to these very parameter objects: a replaced model (or a re-estimated one, which
+        # gets new lists) invalidates it even when the number of models is unchanged
+        srcs = [(m._multivariate_normals, m._log_transition_probs) for m in self._models]
+        if cache is None or len(cache["srcs"]) != len(srcs) or \
+                any(a[0] is not b[0] or a[1] is not b[1] for a, b in zip(cache["srcs"], srcs)):
             sizes = [m.num_of_states for m in self._models]
             if sum(sizes) > _native.MAX_STATES:
                 raise ValueError(f"{sum(sizes)} states in the collection; the decoder handles {_native.MAX_STATES}")
@@ -39,7 +43,7 @@ class ModelCollection:
             ends = np.cumsum(sizes)
             start = np.zeros(int(ends[-1]), dtype=np.uint8)
             start[np.concatenate([[0], ends[:-1]])] = 1
-            cache = {"n": len(self._models), "token": _native.new_token(),
+            cache = {"srcs": srcs, "token": _native.new_token(),
                      "model": stack_gaussians([g for m in self._models for g in m._multivariate_normals]),
                      "band": band, "start": start, "last": ends - 1}
             self.__dict__["_dev_cache"] = cache

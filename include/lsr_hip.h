@@ -133,10 +133,19 @@ int lsr_emission_batch(lsr_ctx* ctx, const float* feats_d, int64_t total_frames,
  * for a batch.  Outputs (any may be NULL): scores_d float32[B]; paths_d int8[total_frames]
  * (ragged like the features); labels_d uint8[B][label_cap] word indices in decode order with
  * the silence word removed; n_labels_d int32[B] = number of labels found (may exceed
- * label_cap; only the first label_cap are stored). */
+ * label_cap; only the first label_cap are stored).  max_frames must be >= the longest utterance: an
+ * utterance that is longer gets score NaN and n_labels -1 and no path (the device checks this against
+ * frame_off_d; the same holds for every decoder below). */
 int lsr_decode_loop_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d,
                           int n_utts, int64_t total_frames, int max_frames, float* scores_d,
                           int8_t* paths_d, uint8_t* labels_d, int32_t* n_labels_d, int label_cap);
+
+/* Replaces ModelBoundary.get_labels (model_boundary.py:107-147) alone, for a batch of state paths over the
+ * uploaded loop graph: paths_d int8[total_frames] ragged by frame_off_d[B+1]; labels_d uint8[B][label_cap]
+ * (may be NULL) and n_labels_d int32[B] as lsr_decode_loop_batch writes them (silence word dropped).  The
+ * same device code produces the label records inside the decoders. */
+int lsr_labels_from_paths(lsr_ctx* ctx, const int8_t* paths_d, const int64_t* frame_off_d, int n_utts,
+                          uint8_t* labels_d, int32_t* n_labels_d, int label_cap);
 
 /* Same, starting from audio: lsr_mfcc_batch + lsr_decode_loop_batch with the features kept in
  * the workspace (what project5_test_ndigits_with_sil.py:64-77 does per utterance). */
@@ -195,7 +204,8 @@ int lsr_recognize_batch_noalloc(lsr_ctx* ctx, const float* audio_d, const int64_
  * missing cross-word keys, -inf to forbid), chain_start_d[i] != 0 marks states initialised at
  * frame 0.  The path is traced back from the chain's LAST state.  Outputs (any may be NULL):
  * scores_d float32[B] (likelihood of the last state), paths_d int8[total_frames] (chain
- * positions), final_d float32[B][64] (last-frame likelihood of every chain position). */
+ * positions), final_d float32[B][64] (last-frame likelihood of every chain position).  A chain
+ * with fewer than 1 or more than 64 states gets score NaN and nothing else. */
 int lsr_decode_chain_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d,
                            int n_utts, int64_t total_frames, int max_frames,
                            const int64_t* chain_off_d, int64_t total_chain,
@@ -288,8 +298,8 @@ int lsr_unpack_label_records(lsr_ctx* ctx, const uint8_t* records_d, int world, 
  * none: its energy is NaN and it counts as a frame without speech, as in the reference);
  * scan_off_d int64[B+1] are the prefix sums of those counts.  Frame energy is the float32 mean
  * of |x| rounded exactly as NumPy's float32 mean; thresholds are high * max|clip| and
- * low * max|clip| (doubles, rounded to float32 for the comparison like NumPy does with a Python
- * float).  Outputs per clip: first_d (first kept frame, -1 if speech never starts), end_d (the
+ * low * max|clip| in float64, and the float32 energy is promoted to float64 for the comparison (the
+ * reference's maximum is an np.float64, signal_separation.py:105,71-76).  Outputs per clip: first_d (first kept frame, -1 if speech never starts), end_d (the
  * frame that tripped the silence counter; kept samples are frames [first, end); -1 if it never
  * tripped) and status_d: 0 = kept, 1 = never tripped (the reference raises FailToProcess,
  * :99-100), 2 = fewer than min_kept_frames kept frames (:95-97, 9 in the reference).

@@ -14,8 +14,8 @@ What the reference does (signal_separation.py:88-164), restated:
   holds the remaining samples and may be EMPTY (its mean is NaN and compares False, so it counts
   as a frame without speech) (:103-109);
 * frame energy = ``np.average(np.abs(frame))``: a float32 mean (NumPy's pairwise float32 sum
-  divided by the count in float32), compared against ``threshold * max|signal|`` — a Python
-  float that NumPy converts to float32 for the comparison (:153-164);
+  divided by the count in float32), compared against ``threshold * max|signal|`` — an np.float64
+  (the maximum is ``np.max(...).astype(float)``), so the comparison runs in float64 (:71-76,105,153-164);
 * a two-threshold state machine: speech starts above the high threshold, continues above the
   low one; frames from the first start on are kept; ``maximum_silence_frames`` consecutive
   frames without speech end the clip, and the frame that trips the counter is not kept (:117-145);
@@ -53,8 +53,10 @@ def scan(energy: np.ndarray, max_volume: float, high: float, low: float,
 
     Statuses: OK, NO_END (the counter never tripped: signal_separation.py:100), TOO_SHORT (:95-97).
     first/end are -1 where they do not exist."""
-    thr_high = np.float32(high * max_volume)        # the comparison runs in float32 (weak Python float)
-    thr_low = np.float32(low * max_volume)
+    # _max_volume is np.max(...).astype(float), an np.float64, so threshold * _max_volume is an np.float64 too
+    # and `average_energy > threshold` promotes the float32 energy to float64 (signal_separation.py:71-76,159-161)
+    thr_high = np.float64(high) * np.float64(max_volume)
+    thr_low = np.float64(low) * np.float64(max_volume)
     n = energy.shape[0]
     noise = np.zeros(n, np.uint8)
     between = ever = False

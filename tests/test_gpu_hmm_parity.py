@@ -78,6 +78,76 @@ def test_g3_loop_decode():
     assert inf.predict(xs[4]) == str(g["u4_m100_labels"])
 
 
+def test_g3_from_models_saved_by_the_reference():
+    """tests/golden/models_g3 holds the twelve G3 word models as the reference's own save() wrote them, converted
+    by tools/convert_reference_models.py: loaded with from_folder they must reproduce the reference's scores, paths
+    and label strings exactly."""
+    import os
+
+    from helpers import GOLDEN
+    from loe_speech_recognition_amd import HiddenMarkovModelInference
+
+    g = load("hmm_g3_loop.npz")
+    inf = HiddenMarkovModelInference.from_folder(os.path.join(GOLDEN, "models_g3"), list(LOOP_LABELS))
+    assert inf._model_boundaries._labels == list(LOOP_LABELS)
+    n = int(g["n_utts"])
+    xs = [g[f"u{i}_x"] for i in range(n)]
+    for tag, between in BETWEEN.items():
+        inf._log_transition_probability_between_words = between
+        labels = inf.predict_batch(xs)
+        vit = inf.viterbi_batch(xs)
+        for i in range(n):
+            assert vit[i][0] == g[f"u{i}_{tag}_score"], (i, tag)
+            assert np.array_equal(vit[i][1], g[f"u{i}_{tag}_path"]), (i, tag)
+            assert labels[i] == str(g[f"u{i}_{tag}_labels"]), (i, tag)
+
+
+def test_g4_device_label_pass():
+    """The device label pass (the code that writes the decoders' label records) over the hand-written G4 paths:
+    the reference's strings exactly, with and without room for every label in the record."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, _native
+
+    g4 = load("hmm_g4_labels.npz")
+    inf = loop_decoder(load("hmm_g3_loop.npz"))          # uploads the 12-word graph (5 states per word, 3 for S)
+    eng = inf._bind()
+    names = inf._model_boundaries._labels
+    n = int(g4["n"])
+    paths = [g4[f"p{i}"].astype(np.int8) for i in range(n)]
+    for cap in (32, 2):
+        labels, count = eng.labels_from_paths(paths, label_cap=cap)
+        labels, count = labels.cpu().numpy(), count.cpu().numpy()
+        for i in range(n):
+            want = str(g4[f"l{i}"])
+            assert count[i] == len(want), (i, want)
+            assert "".join(names[w] for w in labels[i, :min(cap, count[i])]) == want[:cap], (i, cap)
+    # a path holding -1 (one-frame utterance) or a state outside the graph emits nothing for those frames
+    labels, count = eng.labels_from_paths([np.array([-1], np.int8), np.array([0, 0, 100, 5], np.int8)])
+    assert count.cpu().numpy().tolist() == [0, 1]          # the change of word after the foreign state has no valid predecessor
+
+
+def test_dense_and_triangular_whitening_decode_identically(monkeypatch):
+    """2 048 synthetic clips decoded with SciPy's whitening matrices uploaded unchanged (all 100 blocks per state)
+    and with their lower-triangular rotation (55 blocks, the default): identical scores, paths and strings."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, _native, synthetic
+
+    models = synthetic.load_word_models()
+    sigs = []
+    for cfg, count, digits in ((2, 512, 1), (3, 1024, 4), (5, 512, 7)):
+        sigs += synthetic.batch(cfg, count, digits, start=5000)[0]
+    results = []
+    for dense in ("1", "0"):
+        monkeypatch.setenv("LSR_DENSE_WHITEN", dense)
+        inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
+        inf._log_transition_probability_between_words = -100
+        eng = inf._bind()
+        fb = eng.mfcc(eng.audio_batch(sigs))
+        scores, paths, labels, n_labels = eng.decode_loop(fb, want_paths=True)
+        results.append((scores.cpu().numpy(), paths.cpu().numpy(), inf._labels_from_device(eng, fb, labels, n_labels, 32)))
+    (s0, p0, l0), (s1, p1, l1) = results
+    assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    assert np.array_equal(p0, p1) and l0 == l1 and len(l0) == 2048
+
+
 def test_g5_isolated_train_step():
     g = load("hmm_g5_training.npz")
     m = trainable("w", g["a_means0"], g["a_cov0"], g["a_trans0"])

@@ -27,3 +27,36 @@ def test_train_test_sweep(tmp_path):
         assert len(truth) == 12 and accuracy >= 0.9, (n, list(zip(truth, prediction)))
     penalties, results = load("project5_find_trans_ndigits_with_sil").main(corpus, models, penalties=[0, -50, -100, -1e5])
     assert len(results) == 4 and results[2] >= 90.0 and results[3] == 0.0      # -1e5 forbids leaving the first word
+
+    # isolated classification of the seen and the unseen split with the eleven word models (project3_predict_simple)
+    simple = load("project3_predict_simple").main(corpus, models)
+    for name in ("seen", "unseen"):
+        truth, pred, accuracy = simple[name]
+        assert len(truth) == 11 * 12 and set(truth) == set("123456789OZ") and accuracy >= 0.95, (name, accuracy)
+    # per-clip calls agree with the batched ones
+    from loe_speech_recognition_amd import MFCC, ModelCollection, TIDigits
+    mc = ModelCollection.load_from_files(models)
+    clips = TIDigits(corpus, isLazyLoading=True).test_dataset["7"][:3]
+    assert [mc.predict(MFCC(c, 16000).feature_vector.T) for c in clips] == simple["unseen"][1][6 * 12:6 * 12 + 3]
+
+    # continuous re-training on 2- and 4-digit training clips (project6_train), from the packaged word models:
+    # the re-estimated models are saved and still decode the test strings
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainable, synthetic
+    strings = load("make_synthetic_corpus").write_corpus(str(tmp_path / "strings"), isolated_per_word=1,
+                                                         strings_per_length=80, seed=11)
+    for model in synthetic.load_word_models().values():
+        model.save(str(tmp_path / "cache" / "packaged"))
+    project6 = load("project6_train")
+    trained = project6.main(strings, str(tmp_path / "cache"), model_name="packaged", max_iterations=3)
+    assert trained.endswith("packaged_continuous_2")
+    assert sorted(os.listdir(trained)) == ["1", "2", "3", "4", "5", "6", "7", "8", "9", "O", "S", "Z"]
+    truth, prediction, accuracy = test.main(corpus, trained, n=4)
+    assert accuracy >= 0.9, list(zip(truth, prediction))
+    before = np.load(os.path.join(str(tmp_path / "cache" / "packaged"), "4", "model.npz"))["mean"]
+    assert not np.array_equal(np.load(os.path.join(trained, "4", "model.npz"))["mean"], before)
+    # The weak models trained above on a dozen silence-stripped clips per word leave a state without frames in the
+    # forced alignment (the free cross-word transitions skip it): HMMTrainMeanFail propagates as in the reference,
+    # and the driver's try / finally still saves the models
+    with pytest.raises(HiddenMarkovModelTrainable.HMMTrainMeanFail):
+        project6.main(strings, str(tmp_path / "cache"), max_iterations=3)
+    assert len(os.listdir(str(tmp_path / "cache" / "big_model_speech_only_continuous_2"))) == 12

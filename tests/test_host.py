@@ -50,6 +50,19 @@ def test_engine_needs_gpu():
             _native.Engine()
 
 
+def test_engine_refuses_a_child_forked_after_gpu_use(monkeypatch):
+    """HIP does not survive fork(): an engine requested in a process other than the one that first initialised the GPU
+    (which is what a forked child looks like: it inherits the parent's module state) raises instead of faulting."""
+    import os
+
+    from loe_speech_recognition_amd import _native
+
+    monkeypatch.setattr(_native, "_hip_pid", os.getpid() + 1)
+    monkeypatch.setattr(_native, "_engine", None)
+    with pytest.raises(_native.NativeError, match="spawn"):
+        _native.get_engine()
+
+
 def test_model_boundary_labels_match_reference():
     from loe_speech_recognition_amd import ModelBoundary
 

@@ -2,44 +2,79 @@
 log_trans_probs.pickle, multivariate_normals.pickle; hidden_markov_model.py:93-115 of the
 reference) into the flat `<label>/model.npz` files this package reads.
 
-The pickles hold instances of the reference's own classes wrapping SciPy frozen
-distributions, so unpickling needs the reference sources importable.  Only use it on model
-folders you produced yourself: unpickling executes code from the file.
+The pickles hold instances of the reference's own classes wrapping SciPy frozen distributions.
+They are read with a restricted unpickler: the two reference classes are replaced by local
+attribute bags, and the only other globals a file may name are the NumPy array / scalar / random-state
+reconstructors and the installed SciPy classes a frozen multivariate normal is made of.  Anything
+else (`os.system`, `builtins.eval`, ...) raises UnpicklingError before it is looked up, so the
+reference sources are neither imported nor executed.
 
-    python tools/convert_reference_models.py --reference /path/to/CS-304-Speech-Recognition-Code \
-        --src .cache/big_model --dst converted/big_model
+    python tools/convert_reference_models.py --src .cache/big_model --dst converted/big_model
 """
 import argparse
 import importlib
+import io
 import os
 import pickle
-import sys
-import types
-import typing
 
 import numpy as np
 
 
-def import_reference(root: str):
-    """Load the reference's HMM modules without its package __init__ (which needs librosa,
-    sounddevice and Python >= 3.12)."""
-    import typing_extensions
+class _Bag:
+    """Stand-in for a reference dataclass: unpickling only fills its __dict__."""
 
-    if not hasattr(typing, "Self"):
-        typing.Self = typing_extensions.Self
-    sys.modules.setdefault("uniplot", types.ModuleType("uniplot"))
-    pkg = types.ModuleType("loe_speech_recognition")
-    pkg.__path__ = [os.path.join(root, "src", "loe_speech_recognition")]
-    sys.modules["loe_speech_recognition"] = pkg
-    return importlib.import_module("loe_speech_recognition.hidden_markov_model")
+
+class LogTransitionProbabilities(_Bag):
+    pass
+
+
+class MultivariateNormal(_Bag):
+    pass
+
+
+_STUBS = {
+    ("loe_speech_recognition.transition_probability", "LogTransitionProbabilities"): LogTransitionProbabilities,
+    ("loe_speech_recognition.hidden_markov_model", "MultivariateNormal"): MultivariateNormal,
+}
+# (module, name) pairs of installed library code that a pickled frozen multivariate normal refers to;
+# numpy.core.* are the NumPy 1.x spellings of numpy._core.*
+_ALLOWED = {
+    ("numpy", "dtype"), ("numpy", "ndarray"),
+    ("numpy._core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.numeric", "_frombuffer"),
+    ("numpy.core.multiarray", "scalar"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.numeric", "_frombuffer"),
+    ("numpy.random._pickle", "__randomstate_ctor"), ("numpy.random._pickle", "__bit_generator_ctor"),
+    ("numpy.random._pickle", "__generator_ctor"), ("numpy.random._mt19937", "MT19937"),
+    ("numpy.random.bit_generator", "__pyx_unpickle_SeedSequence"), ("numpy.random.bit_generator", "SeedSequence"),
+    ("numpy.random.mtrand", "RandomState"),
+    ("scipy.stats._multivariate", "multivariate_normal_frozen"), ("scipy.stats._multivariate", "multivariate_normal_gen"),
+    ("scipy.stats._multivariate", "_PSD"), ("scipy.stats._covariance", "CovViaPSD"),
+    ("scipy.stats._covariance", "CovViaEigendecomposition"), ("scipy.stats._covariance", "CovViaCholesky"),
+    ("scipy.stats._covariance", "CovViaDiagonal"), ("scipy.stats._covariance", "CovViaPrecision"),
+}
+
+
+class RestrictedUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        key = (module, name)
+        if key in _STUBS:
+            return _STUBS[key]
+        if key in _ALLOWED:
+            return getattr(importlib.import_module(module), name)
+        raise pickle.UnpicklingError(f"model file refers to {module}.{name}, which a saved model never needs; refusing to load it")
+
+
+def restricted_load(path: str):
+    with open(path, "rb") as f:
+        return RestrictedUnpickler(io.BytesIO(f.read())).load()
 
 
 def convert_folder(src: str, dst: str) -> str:
     label = src.rstrip("/").split("/")[-1]
-    with open(os.path.join(src, "log_trans_probs.pickle"), "rb") as f:
-        ltp = pickle.load(f)
-    with open(os.path.join(src, "multivariate_normals.pickle"), "rb") as f:
-        mvns = pickle.load(f)
+    ltp = restricted_load(os.path.join(src, "log_trans_probs.pickle"))
+    mvns = restricted_load(os.path.join(src, "multivariate_normals.pickle"))
+    if not isinstance(ltp, LogTransitionProbabilities) or not isinstance(mvns, list) or \
+            not all(isinstance(m, MultivariateNormal) for m in mvns):
+        raise ValueError(f"{src}: not a model folder written by the reference's save()")
     n = len(mvns)
     mean = np.stack([np.asarray(m._core.mean, dtype=np.float64) for m in mvns])
     whiten = np.stack([np.asarray(m._core.cov_object._LP, dtype=np.float64) for m in mvns])
@@ -53,18 +88,23 @@ def convert_folder(src: str, dst: str) -> str:
     return out
 
 
+def convert_tree(src: str, dst: str):
+    done = []
+    for name in sorted(os.listdir(src)):
+        path = os.path.join(src, name)
+        if os.path.isfile(os.path.join(path, "multivariate_normals.pickle")):
+            done.append(convert_folder(path, dst))
+    return done
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reference", required=True, help="checkout of the reference repository")
     ap.add_argument("--src", required=True, help="folder with one sub-folder per label (the reference's save() layout)")
     ap.add_argument("--dst", required=True)
+    ap.add_argument("--reference", default=None, help="ignored (kept for older command lines): the reference is not imported")
     args = ap.parse_args()
-    sys.dont_write_bytecode = True
-    import_reference(args.reference)
-    for name in sorted(os.listdir(args.src)):
-        path = os.path.join(args.src, name)
-        if os.path.isfile(os.path.join(path, "multivariate_normals.pickle")):
-            print("wrote", convert_folder(path, args.dst))
+    for out in convert_tree(args.src, args.dst):
+        print("wrote", out)
 
 
 if __name__ == "__main__":

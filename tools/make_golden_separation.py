@@ -57,6 +57,15 @@ def clips(rng):
     out.append(from_levels([L, S, L, S, L, S, L, S, L, S, L, S, L, L, L], rng, jitter=1.0))   # restarts every other frame
     out.append(from_levels([599.0, 601.0, 600.0] * 4 + [S] * 10 + [101.0, 99.0, 100.0] * 2 + [L] * 3, rng))
     out.append((np.rint(rng.uniform(-50, 50, 3 * FS + 5))).astype(np.float32))      # faint noise only
+    # Frames whose float32 energy equals the float32 ROUNDING of a threshold but exceeds the threshold itself:
+    # maximum 5020 -> high threshold 0.06 * 5020 = 301.2 and low threshold 0.01 * 5020 = 50.2 in float64, while
+    # the frame means 48192 / 160 and 8032 / 160 are float32(301.2) = 301.200012 and float32(50.2) = 50.200001.
+    # The reference compares in float64 (its maximum is an np.float64), so both frames count as speech.
+    sign = np.where(np.arange(FS) % 2 == 0, 1.0, -1.0)
+    on_high = sign * np.concatenate([np.full(32, 302.0), np.full(128, 301.0)])
+    on_low = sign * np.concatenate([np.full(32, 51.0), np.full(128, 50.0)])
+    quiet, loud = sign * 20.0, sign * 5020.0
+    out.append(np.concatenate([quiet] * 3 + [on_high] + [on_low] * 3 + [loud] * 8 + [on_low] * 2 + [quiet] * 4).astype(np.float32))
     return out
 
 

@@ -12,7 +12,7 @@ eng=_native.get_engine(); models=synthetic.load_word_models()
 tc=HiddenMarkovModelTrainContinuous(isTqdm=False)
 for lab in synthetic.WORDS+["S"]: tc.add_model(models[lab])
 fb=eng.mfcc(eng.audio_batch(sigs)); labeled={"x":None}
-tc.__dict__["_data_cache"]={"key":id(labeled),"fb":fb,"owner":truth}
+tc.use_device_batch(fb, truth); labeled = None
 tc._iteration(labeled); torch.cuda.synchronize()
 eng.profile_reset(); eng.profile_enable(True)
 pr=cProfile.Profile(); t=time.time(); pr.enable()
