@@ -378,8 +378,9 @@ extern "C" int lsr_loop_graph_upload(lsr_ctx* ctx, int n_states, int n_words, co
     if (n_states > LSR_MAX_STATES)
         return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_loop_graph_upload: %d states > %d", n_states, LSR_MAX_STATES);
     if (silence_word >= n_words) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_loop_graph_upload: silence_word out of range");
-    std::vector<float> b(3 * 64, -INFINITY);
-    std::vector<uint8_t> flags(64, 0), word_of(64, 0), lower_of(64, 0), upper_of(64, 0);
+    const int GS = LSR_GRAPH_STRIDE;
+    std::vector<float> b(3 * GS, -INFINITY);
+    std::vector<uint8_t> flags(GS, 0), word_of(GS, 0), lower_of(GS, 0), upper_of(GS, 0);
     int expect = 0;
     for (int w = 0; w < n_words; ++w) {
         if (word_lower[w] != expect || word_upper[w] < word_lower[w] || word_upper[w] >= n_states)
@@ -398,7 +399,7 @@ extern "C" int lsr_loop_graph_upload(lsr_ctx* ctx, int n_states, int n_words, co
         for (int s = 0; s < n_states; ++s) {
             const float v = band[d * n_states + s];
             if (v != v) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_loop_graph_upload: NaN transition");
-            b[d * 64 + s] = v;
+            b[d * GS + s] = v;
         }
     int rc;
     if ((rc = upload(ctx, &ctx->d_band, b.data(), b.size(), "band"))) return rc;
@@ -452,17 +453,19 @@ extern "C" int lsr_emission_batch(lsr_ctx* ctx, const float* feats_d, int64_t to
     if (!ctx) return LSR_ERR_ARG;
     if (!feats_d || !ll_d) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_emission_batch: null pointer");
     if (ctx->n_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_emission_batch: no model uploaded");
-    if (ctx->n_states / ctx->n_mix > LSR_LL_STRIDE)
-        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_emission_batch: %d states > %d", ctx->n_states / ctx->n_mix, LSR_LL_STRIDE);
+    if (ctx->n_states / ctx->n_mix > 128)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_emission_batch: %d states > 128", ctx->n_states / ctx->n_mix);
     int rc = check_batch(ctx, "lsr_emission_batch", 1, total_frames);
     if (rc) return rc;
     LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     return lsr_launch_emission(ctx, feats_d, total_frames, ll_d);
 }
 
-static size_t ll_bytes(int64_t total_frames) {
-    return (size_t)((total_frames + 63) / 64 * 64) * LSR_LL_STRIDE * sizeof(float);
+static size_t ll_bytes(const lsr_ctx* ctx, int64_t total_frames) {
+    return (size_t)((total_frames + 63) / 64 * 64) * lsr_ctx_ll_stride(ctx) * sizeof(float);
 }
+
+extern "C" int lsr_ll_stride(const lsr_ctx* ctx) { return ctx ? lsr_ctx_ll_stride(ctx) : LSR_LL_STRIDE; }
 
 extern "C" int lsr_decode_loop_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d, int n_utts,
                                      int64_t total_frames, int max_frames, float* scores_d, int8_t* paths_d,
@@ -478,7 +481,7 @@ extern "C" int lsr_decode_loop_batch(lsr_ctx* ctx, const float* feats_d, const i
     if (rc) return rc;
     if (max_frames < 1) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_loop_batch: max_frames < 1");
     LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(total_frames), "emission scores"))) return rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(ctx, total_frames), "emission scores"))) return rc;
     if ((rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr))) return rc;
     return lsr_launch_viterbi_loop(ctx, (const float*)ctx->ws_ll.ptr, frame_off_d, n_utts, total_frames, max_frames,
                                    scores_d, paths_d, labels_d, n_labels_d, label_cap);
@@ -503,7 +506,7 @@ extern "C" int lsr_decode_loop_sweep(lsr_ctx* ctx, const float* feats_d, const i
     int rc = check_batch(ctx, "lsr_decode_loop_sweep", n_utts, total_frames);
     if (rc) return rc;
     LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(total_frames), "emission scores"))) return rc;
+    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(ctx, total_frames), "emission scores"))) return rc;
     if ((rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr))) return rc;
     const double saved = ctx->between;
     const int saved_wide = ctx->between_is_f64;
@@ -527,8 +530,8 @@ int lsr_reserve_recognize(lsr_ctx* ctx, int n_utts, int64_t total_frames) {
     if ((rc = lsr_reserve(ctx, &ctx->ws_uttmax, (size_t)n_utts * sizeof(unsigned int), "utterance maxima"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_frame_info, (size_t)total_frames * 16, "frame records"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_feats, (size_t)total_frames * LSR_DIM * sizeof(float), "features"))) return rc;
-    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(total_frames), "emission scores"))) return rc;
-    return lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * 64, "back-pointers");
+    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(ctx, total_frames), "emission scores"))) return rc;
+    return lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * (ctx->g_states > 64 ? 128 : 64), "back-pointers");
 }
 
 static int recognize_any(lsr_ctx* ctx, const void* audio_d, int is_i16, const int64_t* sample_off_d,
@@ -561,25 +564,43 @@ extern "C" int lsr_recognize_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, con
                          labels_d, n_labels_d, label_cap);
 }
 
+static int decode_chain_any(lsr_ctx* ctx, const char* fn, bool wide, const float* feats_d, const int64_t* frame_off_d,
+                            int n_utts, int64_t total_frames, int max_frames, const int64_t* chain_off_d,
+                            int64_t total_chain, const int32_t* chain_state_d, const float* chain_band_d,
+                            const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d, float* final_d) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!feats_d || !frame_off_d || !chain_off_d || !chain_state_d || !chain_band_d || !chain_start_d)
+        return lsr_fail(ctx, LSR_ERR_ARG, "%s: null pointer", fn);
+    if (ctx->n_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "%s: no model uploaded", fn);
+    if (ctx->n_states / ctx->n_mix > 128)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "%s: %d model states > 128", fn, ctx->n_states / ctx->n_mix);
+    int rc = check_batch(ctx, fn, n_utts, total_frames);
+    if (rc) return rc;
+    if (max_frames < 1 || total_chain < n_utts) return lsr_fail(ctx, LSR_ERR_ARG, "%s: bad sizes", fn);
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(ctx, total_frames), "emission scores"))) return rc;
+    if ((rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr))) return rc;
+    return lsr_launch_viterbi_chain(ctx, (const float*)ctx->ws_ll.ptr, frame_off_d, n_utts, total_frames, max_frames,
+                                    chain_off_d, total_chain, chain_state_d, chain_band_d, chain_start_d, scores_d,
+                                    paths_d, final_d, wide);
+}
+
 extern "C" int lsr_decode_chain_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d, int n_utts,
                                       int64_t total_frames, int max_frames, const int64_t* chain_off_d,
                                       int64_t total_chain, const int32_t* chain_state_d, const float* chain_band_d,
                                       const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d, float* final_d) {
-    if (!ctx) return LSR_ERR_ARG;
-    if (!feats_d || !frame_off_d || !chain_off_d || !chain_state_d || !chain_band_d || !chain_start_d)
-        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_chain_batch: null pointer");
-    if (ctx->n_states == 0) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_decode_chain_batch: no model uploaded");
-    if (ctx->n_states / ctx->n_mix > LSR_LL_STRIDE)
-        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_decode_chain_batch: %d model states > %d", ctx->n_states / ctx->n_mix, LSR_LL_STRIDE);
-    int rc = check_batch(ctx, "lsr_decode_chain_batch", n_utts, total_frames);
-    if (rc) return rc;
-    if (max_frames < 1 || total_chain < n_utts) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_decode_chain_batch: bad sizes");
-    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(total_frames), "emission scores"))) return rc;
-    if ((rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr))) return rc;
-    return lsr_launch_viterbi_chain(ctx, (const float*)ctx->ws_ll.ptr, frame_off_d, n_utts, total_frames, max_frames,
-                                    chain_off_d, total_chain, chain_state_d, chain_band_d, chain_start_d, scores_d,
-                                    paths_d, final_d);
+    return decode_chain_any(ctx, "lsr_decode_chain_batch", false, feats_d, frame_off_d, n_utts, total_frames, max_frames,
+                            chain_off_d, total_chain, chain_state_d, chain_band_d, chain_start_d, scores_d, paths_d,
+                            final_d);
+}
+
+extern "C" int lsr_decode_chain_batch_wide(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d, int n_utts,
+                                           int64_t total_frames, int max_frames, const int64_t* chain_off_d,
+                                           int64_t total_chain, const int32_t* chain_state_d, const float* chain_band_d,
+                                           const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d) {
+    return decode_chain_any(ctx, "lsr_decode_chain_batch_wide", true, feats_d, frame_off_d, n_utts, total_frames,
+                            max_frames, chain_off_d, total_chain, chain_state_d, chain_band_d, chain_start_d, scores_d,
+                            paths_d, nullptr);
 }
 
 extern "C" int lsr_accumulate_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, int64_t total_frames,

@@ -57,7 +57,7 @@ template <bool TRI, bool MIX>
 __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
     const double* __restrict__ lognorm, const double* __restrict__ logw,
-    int n_states, int n_mix, float* __restrict__ ll) {
+    int n_states, int n_mix, float* __restrict__ ll, int ll_stride) {
     // [frame][(state - first state of the run) ^ frame]: the XOR keeps the per-row reads on distinct LDS
     // banks without padding; 8 KiB per wavefront, so three workgroups fit a compute unit
     __shared__ float tile[EM_WAVES][64][EM_RUN];
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
             }
         }
         // write-out of columns c0..c1-1 of the wavefront's own tile, one row per instruction (lane = column
-        // c0 + lane); the run that ends a tile also fills the padding columns up to 64 with -inf.  Only
+        // c0 + lane); the run that ends a tile also fills the padding columns up to the row stride with -inf.  Only
         // this wavefront touches tile[wave].
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -194,11 +194,11 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
         if (lane < c1 - c0) {
 #pragma unroll 8
             for (int r = 0; r < 64; ++r)
-                ll[(f0 + r) * LSR_LL_STRIDE + c0 + lane] = tile[wave][r][(lane ^ r) & (EM_RUN - 1)];
+                ll[(f0 + r) * ll_stride + c0 + lane] = tile[wave][r][(lane ^ r) & (EM_RUN - 1)];
         }
-        if (c1 == n_cols && n_cols + lane < LSR_LL_STRIDE) {
+        if (c1 == n_cols && n_cols + lane < ll_stride) {
 #pragma unroll 8
-            for (int r = 0; r < 64; ++r) ll[(f0 + r) * LSR_LL_STRIDE + n_cols + lane] = -INFINITY;
+            for (int r = 0; r < 64; ++r) ll[(f0 + r) * ll_stride + n_cols + lane] = -INFINITY;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -214,12 +214,12 @@ int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames
     const int64_t pairs = (total_frames + 63) / 64 * (ctx->n_states / ctx->n_mix);
     int64_t blocks = (pairs + EM_WAVES - 1) / EM_WAVES;
     if (blocks > per_cu * (int64_t)ctx->n_cus) blocks = per_cu * (int64_t)ctx->n_cus;
-    void (*kern)(const float*, int64_t, const double*, const double*, const double*, int, int, float*) =
+    void (*kern)(const float*, int64_t, const double*, const double*, const double*, int, int, float*, int) =
         ctx->whiten_triangular ? (mix ? lsr_emission_kernel<true, true> : lsr_emission_kernel<true, false>)
                                : (mix ? lsr_emission_kernel<false, true> : lsr_emission_kernel<false, false>);
     lsr_prof_begin(ctx, LSR_K_EMISSION);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream, feats_d, total_frames,
-                       ctx->d_wfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d);
+                       ctx->d_wfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d, lsr_ctx_ll_stride(ctx));
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_emission_kernel");
     return LSR_OK;

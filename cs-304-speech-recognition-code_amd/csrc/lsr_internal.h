@@ -13,6 +13,7 @@
 #define LSR_JBLOCKS 10       // whitened components padded to 10 blocks of 4
 #define LSR_TRI_SLOTS 56     // blocks per state of a triangular whitening matrix (55) rounded up
 #define LSR_KSTEPS 10        // LSR_KPAD / 4
+#define LSR_GRAPH_STRIDE 128 // row stride of the loop-graph tables (band, flags, word maps)
 
 struct lsr_buffer {
     void* ptr = nullptr;
@@ -44,11 +45,11 @@ struct lsr_ctx {
 
     // loop graph (device)
     int g_states = 0, g_words = 0, g_silence = -1;
-    float* d_band = nullptr;         // [3][64]
-    uint8_t* d_flags = nullptr;      // [64] bit0 = word entry state, bit1 = word exit state
-    uint8_t* d_word_of = nullptr;    // [64] word index of each state
-    uint8_t* d_lower_of = nullptr;   // [64] first state of the state's word
-    uint8_t* d_upper_of = nullptr;   // [64] last state of the state's word
+    float* d_band = nullptr;         // [3][128]
+    uint8_t* d_flags = nullptr;      // [128] bit0 = word entry state, bit1 = word exit state
+    uint8_t* d_word_of = nullptr;    // [128] word index of each state
+    uint8_t* d_lower_of = nullptr;   // [128] first state of the state's word
+    uint8_t* d_upper_of = nullptr;   // [128] last state of the state's word
     double between = -5.298317366548036;   // log(0.005)
     int between_is_f64 = 1;
 
@@ -137,6 +138,11 @@ struct lsr_mfcc_ws {
 int lsr_launch_mfcc_ws(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, const int64_t* sample_off_d,
                        const int64_t* frame_off_d, int n_utts, int64_t total_frames, float* feats_d,
                        const lsr_mfcc_ws& ws);
+// Row stride (floats) of emission score matrices for the uploaded model: 64, or 128 when the model has more than
+// 64 states (columns beyond the states are -inf either way).
+static inline int lsr_ctx_ll_stride(const lsr_ctx* ctx) {
+    return ctx->n_states / (ctx->n_mix > 0 ? ctx->n_mix : 1) > 64 ? 128 : 64;
+}
 int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d);
 int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
                             int64_t total_frames, int max_frames, float* scores_d, int8_t* paths_d,
@@ -145,7 +151,7 @@ int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* fra
                              int64_t total_frames, int max_frames, const int64_t* chain_off_d,
                              int64_t total_chain, const int32_t* chain_state_d,
                              const float* chain_band_d, const uint8_t* chain_start_d,
-                             float* scores_d, int8_t* paths_d, float* final_d);
+                             float* scores_d, int8_t* paths_d, float* final_d, bool wide = false);
 int lsr_launch_utt_index(lsr_ctx* ctx, const int64_t* off_d, int n_utts, int32_t* out_d);
 int lsr_launch_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, int64_t total_frames,
                      int n_slots, double* count_d, double* sum_x_d, double* sum_xx_d);

@@ -59,6 +59,9 @@ extern "C" int lsr_recognize_batch_noalloc(lsr_ctx* ctx, const float* audio_d, c
     if (ctx->n_states / ctx->n_mix != ctx->g_states)
         return lsr_fail(ctx, LSR_ERR_STATE, "lsr_recognize_batch_noalloc: model has %d states, graph %d",
                         ctx->n_states / ctx->n_mix, ctx->g_states);
+    if (ctx->g_states > 64)
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_recognize_batch_noalloc: graphs above 64 states need the growing workspace; "
+                                            "use lsr_recognize_batch");
     if (ctx->profiling)      // per-kernel timing creates HIP events on demand
         return lsr_fail(ctx, LSR_ERR_STATE, "lsr_recognize_batch_noalloc: disable profiling first (it creates events)");
     if (ctx->device < 0 || ctx->device >= NA_MAX_DEVICES || !g_scratch_ptr[ctx->device])

@@ -1,5 +1,6 @@
 // Viterbi recursion, back-trace and label extraction: one wavefront per utterance, one lane per
-// state (at most 64 states).
+// state (at most 64 states; a second, two-wavefront form further down takes 65..127 states, the
+// most the reference's int8 back-pointers can address).
 //
 // Recursion for state s at frame t (all float32 adds, first maximal candidate wins):
 //   interior / chain states: best = max_{d=2,1,0} band[d][s] + prev[s-d]
@@ -19,6 +20,7 @@
 
 struct vit_args {
     const float* ll;
+    int ll_stride;     // floats per row of ll (64, or 128 for models above 64 states)
     const int64_t* frame_off;
     // loop graph
     const float* band;
@@ -221,8 +223,8 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
         const bool live = lane < n;
         gid = live ? lane : 0;
         a0 = A.band[lane];
-        a1 = A.band[64 + lane];
-        a2 = A.band[128 + lane];
+        a1 = A.band[LSR_GRAPH_STRIDE + lane];
+        a2 = A.band[2 * LSR_GRAPH_STRIDE + lane];
         const unsigned f = A.flags[lane];
         is_entry = live && (f & 1);
         is_exit = live && (f & 2);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
     if (lane < 1) a1 = -INFINITY;
     if (lane < 2) a2 = -INFINITY;
 
-    const float* llrow = A.ll + off * LSR_LL_STRIDE + gid;
+    const float* llrow = A.ll + off * A.ll_stride + gid;
     int8_t* trrow = A.tracer + off * 64 + lane;
 
     // frame 0: start states get emission + self-loop term
@@ -244,14 +246,14 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
 #pragma unroll
     for (int i = 0; i < VIT_PREFETCH; ++i) {
         const int t = 1 + i < T ? 1 + i : T - 1;
-        ecur[i] = llrow[(int64_t)t * LSR_LL_STRIDE];
+        ecur[i] = llrow[(int64_t)t * A.ll_stride];
     }
     int t0 = 1;
     for (; t0 + VIT_PREFETCH <= T; t0 += VIT_PREFETCH) {
 #pragma unroll
         for (int i = 0; i < VIT_PREFETCH; ++i) {
             const int t = t0 + VIT_PREFETCH + i < T ? t0 + VIT_PREFETCH + i : T - 1;      // clamped: no branch
-            enxt[i] = llrow[(int64_t)t * LSR_LL_STRIDE];
+            enxt[i] = llrow[(int64_t)t * A.ll_stride];
         }
 #pragma unroll
         for (int i = 0; i < VIT_PREFETCH; ++i)
@@ -314,6 +316,192 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
     if (MODE != VIT_CHAIN && (A.labels || A.n_labels)) vit_labels(A, pathbuf, T, b, lane);
 }
 
+// ---- graphs and chains of 65..127 states: two wavefronts per utterance -------------------------------------
+// Same recursion, back-trace and label pass with thread = state over 128 threads.  The neighbour scores
+// prev[s-1], prev[s-2] and the per-wavefront word-exit maxima cross the wavefront boundary through LDS
+// (double-buffered by frame parity: one barrier per frame).  The back-pointer table has 128 columns.
+#define VW_PREV_LD 132
+
+template <typename T>
+__device__ __forceinline__ void vw_combine(T m0, int f0, T m1, int f1, T& m, int& first) {
+    // the lowest state among equal maxima wins: wavefront 0 holds the lower states
+    const bool take0 = f0 >= 0 && (f1 < 0 || m0 >= m1);
+    m = take0 ? m0 : m1;
+    first = take0 ? f0 : f1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(128) void lsr_viterbi_wide_kernel(vit_args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int8_t* pathbuf = (int8_t*)smem;
+    int8_t* trblk = (int8_t*)smem + A.path_cap;                            // [64][128]
+    float* prevbuf = (float*)(smem + A.path_cap + 64 * 128);                // [2][VW_PREV_LD], entry 2 + s = state s
+    double* redm = (double*)(prevbuf + 2 * VW_PREV_LD);                     // [2][2] per-wavefront exit maximum
+    int* redi = (int*)(redm + 4);                                           // [2][2] state that holds it (-1: none)
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
+    const int64_t off = A.frame_off[b];
+    const int T = (int)(A.frame_off[b + 1] - off);
+    if (T < 1) return;
+    bool bad = T > A.path_cap;
+    if (MODE == VIT_CHAIN) {
+        const int64_t len = A.chain_off[b + 1] - A.chain_off[b];
+        bad = bad || len < 1 || len > 127;
+    }
+    if (bad) {
+        if (tid == 0) {
+            if (A.scores) A.scores[b] = __builtin_nanf("");
+            if (A.n_labels) A.n_labels[b] = -1;
+        }
+        return;
+    }
+
+    int n, gid;
+    float a0, a1, a2;
+    bool is_start, is_entry = false, is_exit = false;
+    if (MODE == VIT_CHAIN) {
+        const int64_t c0 = A.chain_off[b];
+        n = (int)(A.chain_off[b + 1] - c0);
+        const bool live = tid < n;
+        const int64_t i = c0 + (live ? tid : 0);
+        gid = live ? A.chain_state[i] : 0;
+        a0 = live ? A.chain_band[i] : -INFINITY;
+        a1 = live ? A.chain_band[A.total_chain + i] : -INFINITY;
+        a2 = live ? A.chain_band[2 * A.total_chain + i] : -INFINITY;
+        is_start = live && A.chain_start[i] != 0;
+    } else {
+        n = A.n_states;
+        const bool live = tid < n;
+        gid = live ? tid : 0;
+        a0 = A.band[tid];
+        a1 = A.band[LSR_GRAPH_STRIDE + tid];
+        a2 = A.band[2 * LSR_GRAPH_STRIDE + tid];
+        const unsigned f = A.flags[tid];
+        is_entry = live && (f & 1);
+        is_exit = live && (f & 2);
+        is_start = is_entry;
+    }
+    if (tid < 1) a1 = -INFINITY;
+    if (tid < 2) a2 = -INFINITY;
+    if (tid < 4) prevbuf[(tid >> 1) * VW_PREV_LD + (tid & 1)] = -INFINITY;      // the two entries below state 0
+
+    const float* llrow = A.ll + off * A.ll_stride + gid;
+    int8_t* trrow = A.tracer + off * 128 + tid;
+    float prev = is_start ? llrow[0] + a0 : -INFINITY;
+    float e_next = llrow[(int64_t)(T > 1 ? 1 : 0) * A.ll_stride];
+
+    for (int t = 1; t < T; ++t) {
+        const float e = e_next;
+        e_next = llrow[(int64_t)(t + 1 < T ? t + 1 : t) * A.ll_stride];          // one frame ahead
+        float* pb = prevbuf + (t & 1) * VW_PREV_LD;
+        pb[2 + tid] = prev;
+        if (MODE == VIT_LOOP32) {
+            const float cand = is_exit ? A.between32 + prev : -INFINITY;
+            const float m = wave_max(cand);
+            const int first = __ffsll((long long)__ballot(is_exit && cand == m)) - 1;
+            if (lane == 0) {
+                redm[(t & 1) * 2 + wave] = (double)m;
+                redi[(t & 1) * 2 + wave] = first >= 0 ? first + 64 * wave : -1;
+            }
+        } else if (MODE == VIT_LOOP64) {
+            const double cand = is_exit ? A.between64 + (double)prev : -(double)INFINITY;
+            const double m = wave_max(cand);
+            const int first = __ffsll((long long)__ballot(is_exit && cand == m)) - 1;
+            if (lane == 0) {
+                redm[(t & 1) * 2 + wave] = m;
+                redi[(t & 1) * 2 + wave] = first >= 0 ? first + 64 * wave : -1;
+            }
+        }
+        __syncthreads();
+        const float p1 = pb[1 + tid], p2 = pb[tid];
+        const float v0 = a0 + prev, v1 = a1 + p1, v2 = a2 + p2;
+        float best = fmaxf(fmaxf(v2, v1), v0);
+        int ptr = (v2 == best) ? tid - 2 : ((v1 == best) ? tid - 1 : tid);
+        if (best == -INFINITY) ptr = 0;
+        float cur;
+        if (MODE == VIT_CHAIN) {
+            cur = best + e;
+        } else {
+            double m;
+            int first;
+            vw_combine(redm[(t & 1) * 2], redi[(t & 1) * 2], redm[(t & 1) * 2 + 1], redi[(t & 1) * 2 + 1], m, first);
+            if (MODE == VIT_LOOP32) {
+                if (is_entry) {
+                    const float mf = (float)m;                     // exact: it is a float32 value
+                    const bool cross = mf >= v0;
+                    best = cross ? mf : v0;
+                    ptr = cross ? first : tid;
+                }
+                cur = best + e;
+            } else {
+                double bestd = (double)best;
+                if (is_entry) {
+                    const bool cross = m >= (double)v0;
+                    bestd = cross ? m : (double)v0;
+                    ptr = cross ? first : tid;
+                }
+                cur = (float)(bestd + (double)e);
+            }
+        }
+        trrow[(int64_t)t * 128] = (int8_t)ptr;
+        prev = cur;
+    }
+
+    // ---- termination -------------------------------------------------------------------------------
+    float* fin = prevbuf + (T & 1) * VW_PREV_LD;
+    int term;
+    float score;
+    if (MODE == VIT_CHAIN) {
+        fin[2 + tid] = prev;
+        __syncthreads();
+        term = n - 1;
+        score = fin[2 + term];
+    } else {
+        const float ends = is_exit ? prev : -INFINITY;
+        const float m = wave_max(ends);
+        const int first = __ffsll((long long)__ballot(is_exit && ends == m)) - 1;
+        if (lane == 0) {
+            redm[(T & 1) * 2 + wave] = (double)m;
+            redi[(T & 1) * 2 + wave] = first >= 0 ? first + 64 * wave : -1;
+        }
+        __syncthreads();
+        double md;
+        vw_combine(redm[(T & 1) * 2], redi[(T & 1) * 2], redm[(T & 1) * 2 + 1], redi[(T & 1) * 2 + 1], md, term);
+        score = (float)md;
+        if (term < 0) term = 0;
+    }
+    if (A.scores && tid == 0) A.scores[b] = score;
+    if (!A.paths && !A.labels && !A.n_labels) return;
+
+    // ---- back-trace: blocks of 64 frames staged in LDS, walked by every thread alike ---------------------
+    __syncthreads();
+    int cur = -1;
+    for (int blk = (T - 1) >> 6; blk >= 0; --blk) {
+        const int base = blk << 6;
+        for (int i = tid; i < 64 * 8; i += 128) {
+            const int r = i >> 3, c = i & 7;
+            if (base + r < T && base + r >= 1)
+                ((uint4*)(trblk + r * 128))[c] = ((const uint4*)(A.tracer + (off + base + r) * 128))[c];
+        }
+        __syncthreads();
+        const int top = (base + 63 < T - 1) ? base + 63 : T - 1;
+        for (int t = top; t >= base; --t) {
+            if (t == T - 1) {
+                cur = (T > 1) ? (int)trblk[(t - base) * 128 + term] : -1;
+                if (tid == 0) pathbuf[t] = (int8_t)cur;
+            } else {
+                if (tid == 0) pathbuf[t] = (int8_t)cur;
+                if (t > 0) cur = (int)trblk[(t - base) * 128 + cur];
+            }
+        }
+        __syncthreads();
+    }
+    if (A.paths)
+        for (int t = tid; t < T; t += 128) A.paths[off + t] = pathbuf[t];
+    if (MODE != VIT_CHAIN && (A.labels || A.n_labels) && wave == 0) vit_labels(A, pathbuf, T, b, lane);
+}
+
 // The label pass on its own: paths in, label records out (one wavefront per utterance, the path is read
 // from memory instead of the decoder's LDS copy).
 __global__ __launch_bounds__(64) void lsr_path_labels_kernel(vit_args A) {
@@ -327,28 +515,39 @@ __global__ __launch_bounds__(64) void lsr_path_labels_kernel(vit_args A) {
     vit_labels(A, A.paths + off, T, b, threadIdx.x);
 }
 
+// tracer_d: back-pointer table int8[total_frames][64] supplied by the caller, or NULL to use the context's workspace.
+// wide: two wavefronts per utterance and a 128-column table (graphs / chains of 65..127 states).
 static int launch(lsr_ctx* ctx, int mode, vit_args& A, int n_utts, int64_t total_frames, int max_frames,
-                  int8_t* tracer_d = nullptr) {
+                  int8_t* tracer_d = nullptr, bool wide = false) {
+    const int cols = wide ? 128 : 64;
     if (!tracer_d) {
-        int rc = lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * 64, "back-pointers");
+        int rc = lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * cols, "back-pointers");
         if (rc) return rc;
         tracer_d = (int8_t*)ctx->ws_tracer.ptr;
+    } else if (wide) {
+        return lsr_fail(ctx, LSR_ERR_LIMIT, "a caller-supplied back-pointer table only serves graphs of at most 64 states");
     }
     A.tracer = tracer_d;
+    A.ll_stride = lsr_ctx_ll_stride(ctx);
     A.path_cap = (max_frames + 63) / 64 * 64;
-    const size_t lds = (size_t)A.path_cap + 64 * 64;
+    const size_t lds = (size_t)A.path_cap + 64 * cols +
+                       (wide ? 2 * VW_PREV_LD * sizeof(float) + 4 * sizeof(double) + 4 * sizeof(int) : 0);
     if (lds > 160 * 1024)
         return lsr_fail(ctx, LSR_ERR_LIMIT, "utterance of %d frames exceeds the %d-frame limit of the decoder", max_frames,
-                        160 * 1024 - 64 * 64 - 64);
-    void (*kern)(vit_args) = mode == VIT_LOOP32 ? lsr_viterbi_kernel<VIT_LOOP32>
-                             : mode == VIT_LOOP64 ? lsr_viterbi_kernel<VIT_LOOP64>
-                                                  : lsr_viterbi_kernel<VIT_CHAIN>;
+                        160 * 1024 - 64 * 128 - 2048);
+    void (*kern)(vit_args);
+    if (wide)
+        kern = mode == VIT_LOOP32 ? lsr_viterbi_wide_kernel<VIT_LOOP32>
+               : mode == VIT_LOOP64 ? lsr_viterbi_wide_kernel<VIT_LOOP64> : lsr_viterbi_wide_kernel<VIT_CHAIN>;
+    else
+        kern = mode == VIT_LOOP32 ? lsr_viterbi_kernel<VIT_LOOP32>
+               : mode == VIT_LOOP64 ? lsr_viterbi_kernel<VIT_LOOP64> : lsr_viterbi_kernel<VIT_CHAIN>;
     if (lds > 64 * 1024)
         LSR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lsr_prof_begin(ctx, LSR_K_VITERBI);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_utts), dim3(64), lds, ctx->stream, A);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_utts), dim3(wide ? 128 : 64), lds, ctx->stream, A);
     lsr_prof_end(ctx);
-    LSR_LAUNCH_CHECK(ctx, "lsr_viterbi_kernel");
+    LSR_LAUNCH_CHECK(ctx, wide ? "lsr_viterbi_wide_kernel" : "lsr_viterbi_kernel");
     return LSR_OK;
 }
 
@@ -372,13 +571,15 @@ int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* fram
     A.labels = labels_d;
     A.n_labels = n_labels_d;
     A.label_cap = label_cap;
-    return launch(ctx, ctx->between_is_f64 ? VIT_LOOP64 : VIT_LOOP32, A, n_utts, total_frames, max_frames, tracer_d);
+    return launch(ctx, ctx->between_is_f64 ? VIT_LOOP64 : VIT_LOOP32, A, n_utts, total_frames, max_frames, tracer_d,
+                  ctx->g_states > 64);
 }
 
 int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
                              int64_t total_frames, int max_frames, const int64_t* chain_off_d, int64_t total_chain,
                              const int32_t* chain_state_d, const float* chain_band_d, const uint8_t* chain_start_d,
-                             float* scores_d, int8_t* paths_d, float* final_d) {
+                             float* scores_d, int8_t* paths_d, float* final_d, bool wide) {
+    if (wide && final_d) return lsr_fail(ctx, LSR_ERR_ARG, "the last-frame score table is only available for chains of at most 64 states");
     vit_args A = {};
     A.ll = ll_d;
     A.frame_off = frame_off_d;
@@ -390,7 +591,7 @@ int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* fra
     A.scores = scores_d;
     A.paths = paths_d;
     A.final_ll = final_d;
-    return launch(ctx, VIT_CHAIN, A, n_utts, total_frames, max_frames);
+    return launch(ctx, VIT_CHAIN, A, n_utts, total_frames, max_frames, nullptr, wide);
 }
 
 extern "C" int lsr_labels_from_paths(lsr_ctx* ctx, const int8_t* paths_d, const int64_t* frame_off_d, int n_utts,

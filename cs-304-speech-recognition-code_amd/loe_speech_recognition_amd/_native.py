@@ -15,8 +15,9 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 DIM = 39
-MAX_STATES = 64
-LL_STRIDE = 64
+MAX_STATES = 127        # per decoding graph / alignment chain (the reference's int8 back-pointers)
+NARROW_STATES = 64      # one wavefront per utterance up to here; two above
+LL_STRIDE = 64          # emission score row stride for models of at most 64 states (128 above)
 HOP = 160
 N_FFT = 320
 MIN_FRAMES = 9          # the width-9 delta filter needs 9 frames (librosa raises below that)
@@ -73,6 +74,8 @@ def _declare(lib) -> None:
         "lsr_pack_label_records": (c_int, [P, P, P, c_int64, c_int, c_int64, P]),
         "lsr_unpack_label_records": (c_int, [P, P, c_int, c_int64, c_int, P, P]),
         "lsr_labels_from_paths": (c_int, [P, P, P, c_int, P, P, c_int]),
+        "lsr_ll_stride": (c_int, [P]),
+        "lsr_decode_chain_batch_wide": (c_int, [P, P, P, c_int, c_int64, c_int, P, c_int64, P, P, P, P, P]),
         "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
         "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_decode_loop_sweep": (c_int, [P, P, P, c_int, c_int64, c_int, POINTER(c_double), POINTER(c_int32), c_int,
@@ -102,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "lsr_recognize_host", "lsr_recognize_host_timing", "lsr_shard_bounds", "lsr_comm_get_unique_id", "lsr_comm_init",
     "lsr_comm_destroy", "lsr_allgather_labels", "lsr_allreduce_stats", "lsr_label_record_bytes",
     "lsr_host_pack_label_records", "lsr_host_unpack_label_records", "lsr_pack_label_records", "lsr_unpack_label_records",
-    "lsr_labels_from_paths",
+    "lsr_labels_from_paths", "lsr_ll_stride", "lsr_decode_chain_batch_wide",
 ]
 
 
@@ -321,7 +324,7 @@ class Engine:
     # -- emission / decoding ----------------------------------------------------------------------
     def emission(self, fb: FeatureBatch):
         rows = (fb.total_frames + 63) // 64 * 64
-        out = self.empty((rows, LL_STRIDE), self.torch.float32)
+        out = self.empty((rows, int(self.lib.lsr_ll_stride(self.ctx))), self.torch.float32)
         self._check(self.lib.lsr_emission_batch(self.ctx, self._ptr(fb.feats), fb.total_frames, self._ptr(out)))
         return out
 
@@ -437,6 +440,9 @@ class Engine:
         lens = np.diff(chain_off)
         if chain_off.shape[0] != fb.n + 1 or lens.min() < 1 or lens.max() > MAX_STATES:
             raise ValueError(f"every chain needs 1..{MAX_STATES} states")
+        wide = int(lens.max()) > NARROW_STATES
+        if wide and want_final:
+            raise ValueError(f"last-frame scores of every chain position are only available up to {NARROW_STATES} states")
         chain_state = np.ascontiguousarray(chain_state, dtype=np.int32)
         if chain_state.shape != (total_chain,) or chain_state.min() < 0 or chain_state.max() >= self.n_model_states:
             raise ValueError("chain_state out of range of the uploaded model")
@@ -452,10 +458,16 @@ class Engine:
         scores = self.empty((fb.n,), t.float32)
         paths = self.empty((fb.total_frames,), t.int8) if want_paths else None
         final = self.empty((fb.n, 64), t.float32) if want_final else None
-        self._check(self.lib.lsr_decode_chain_batch(self.ctx, self._ptr(fb.feats), self._ptr(fb.frame_off), fb.n,
-                                                    fb.total_frames, fb.max_frames, self._ptr(d_off), total_chain,
-                                                    self._ptr(d_state), self._ptr(d_band), self._ptr(d_start),
-                                                    self._ptr(scores), self._ptr(paths), self._ptr(final)))
+        if wide:
+            self._check(self.lib.lsr_decode_chain_batch_wide(self.ctx, self._ptr(fb.feats), self._ptr(fb.frame_off), fb.n,
+                                                             fb.total_frames, fb.max_frames, self._ptr(d_off), total_chain,
+                                                             self._ptr(d_state), self._ptr(d_band), self._ptr(d_start),
+                                                             self._ptr(scores), self._ptr(paths)))
+        else:
+            self._check(self.lib.lsr_decode_chain_batch(self.ctx, self._ptr(fb.feats), self._ptr(fb.frame_off), fb.n,
+                                                        fb.total_frames, fb.max_frames, self._ptr(d_off), total_chain,
+                                                        self._ptr(d_state), self._ptr(d_band), self._ptr(d_start),
+                                                        self._ptr(scores), self._ptr(paths), self._ptr(final)))
         self.synchronize()     # the chain arrays above must outlive the kernels
         return scores, paths, final
 

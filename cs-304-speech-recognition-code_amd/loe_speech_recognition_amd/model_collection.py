@@ -37,8 +37,9 @@ class ModelCollection:
         if cache is None or len(cache["srcs"]) != len(srcs) or \
                 any(a[0] is not b[0] or a[1] is not b[1] for a, b in zip(cache["srcs"], srcs)):
             sizes = [m.num_of_states for m in self._models]
-            if sum(sizes) > _native.MAX_STATES:
-                raise ValueError(f"{sum(sizes)} states in the collection; the decoder handles {_native.MAX_STATES}")
+            if sum(sizes) > _native.NARROW_STATES:
+                raise ValueError(f"{sum(sizes)} states in the collection; scoring all models side by side handles "
+                                 f"{_native.NARROW_STATES}")
             band = np.concatenate([m._log_transition_probs.band() for m in self._models], axis=1)
             ends = np.cumsum(sizes)
             start = np.zeros(int(ends[-1]), dtype=np.uint8)

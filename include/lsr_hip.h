@@ -19,8 +19,10 @@
  *     calls are asynchronous with respect to the host unless stated otherwise.
  *   - internal workspace grows on demand (hipMalloc) and is reused; a steady-state loop over
  *     batches no larger than an earlier one allocates nothing.
- *   - feature dimension is fixed at LSR_DIM = 39, at most LSR_MAX_STATES = 64 states per
- *     decoding graph / alignment chain.
+ *   - feature dimension is fixed at LSR_DIM = 39, at most LSR_MAX_STATES = 127 states per
+ *     decoding graph / alignment chain (the reach of the reference's int8 back-pointers,
+ *     hidden_markov_model.py:498-501).  Graphs and chains of at most 64 states run one wavefront
+ *     per utterance; larger ones a slower two-wavefront form.
  */
 #ifndef LSR_HIP_H
 #define LSR_HIP_H
@@ -32,8 +34,9 @@ extern "C" {
 #endif
 
 #define LSR_DIM 39
-#define LSR_MAX_STATES 64
-#define LSR_LL_STRIDE 64      /* row stride (floats) of emission score matrices */
+#define LSR_MAX_STATES 127
+#define LSR_LL_STRIDE 64      /* row stride (floats) of emission score matrices of models with at most 64
+                                 states; 128 above that: see lsr_ll_stride */
 #define LSR_N_FFT 320
 #define LSR_HOP 160
 #define LSR_N_MELS 40
@@ -98,7 +101,8 @@ int lsr_model_set_mixtures(lsr_ctx* ctx, int n_mix, const double* log_weights);
  * (hidden_markov_model.py:421-456): word models stacked in order, band[d][s] =
  * log a(s-d -> s) for d = 0,1,2 (-inf where s-d is not a candidate predecessor: before the
  * word's first state), word_lower/word_upper[w] = first/last state of word w (ascending).
- * silence_word = index of the word dropped from label output (-1: none). */
+ * silence_word = index of the word dropped from label output (-1: none).  Up to LSR_MAX_STATES
+ * states; the decoders pick the two-wavefront form by themselves above 64. */
 int lsr_loop_graph_upload(lsr_ctx* ctx, int n_states, int n_words, const float* band,
                           const int32_t* word_lower, const int32_t* word_upper, int silence_word);
 /* The writable attribute _log_transition_probability_between_words
@@ -123,9 +127,11 @@ int lsr_mfcc_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, const int64_t* samp
 /* ---- emission scores -------------------------------------------------------------------- */
 /* Replaces MultivariateNormal.log_pdf (hidden_markov_model.py:46-48) for every (frame, state):
  * ll_d[f][s] = float32( -0.5 * (log_norm[s] + |(x_f - mean_s) @ whiten_s|^2) ), float64
- * inside.  ll_d: float32 [round_up(total_frames, 64)][LSR_LL_STRIDE]; columns >= n_states
- * are -inf. */
+ * inside.  ll_d: float32 [round_up(total_frames, 64)][lsr_ll_stride(ctx)]; columns >= n_states
+ * are -inf.  The stride is LSR_LL_STRIDE = 64 for models of at most 64 states (mixture components
+ * do not count) and 128 for larger ones (at most 128 states). */
 int lsr_emission_batch(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d);
+int lsr_ll_stride(const lsr_ctx* ctx);
 
 /* ---- decoding --------------------------------------------------------------------------- */
 /* Replaces HiddenMarkovModelInference.predict/_viterbi/_viterbi_static
@@ -184,8 +190,8 @@ int lsr_recognize_host_timing(lsr_ctx* ctx, double* seconds4, int* n_chunks);
  * in the reference.  Same arguments, same kernels and bit-identical outputs; every intermediate
  * buffer lives in one static device array of about 41 MiB per GPU (held until the process ends)
  * instead of the context's growing workspace, and the call performs no hipMalloc / hipFree.
- * Limits: n_utts <= LSR_NOALLOC_MAX_UTTS and total_frames <= LSR_NOALLOC_MAX_FRAMES
- * (LSR_ERR_LIMIT beyond); profiling must be off (LSR_ERR_STATE).  All calls on one GPU share the
+ * Limits: n_utts <= LSR_NOALLOC_MAX_UTTS, total_frames <= LSR_NOALLOC_MAX_FRAMES and a loop graph of
+ * at most 64 states (LSR_ERR_LIMIT beyond); profiling must be off (LSR_ERR_STATE).  All calls on one GPU share the
  * array: calls that overlap in time on one GPU (other streams, other contexts) race. */
 #define LSR_NOALLOC_MAX_FRAMES 65536
 #define LSR_NOALLOC_MAX_UTTS 4096
@@ -198,7 +204,7 @@ int lsr_recognize_batch_noalloc(lsr_ctx* ctx, const float* audio_d, const int64_
  * 160-208) for a batch of per-utterance chains: isolated word models, several independent
  * models side by side (ModelCollection.predict, model_collection.py:23-28) or the stacked
  * alignment chain S d S d ... S of HiddenMarkovModelMultiWord (hidden_markov_model.py:584-664).
- * Chain b has chain_off_d[b+1]-chain_off_d[b] <= 64 states; for chain position c (ragged
+ * Chain b has chain_off_d[b+1]-chain_off_d[b] <= 64 states (longer: lsr_decode_chain_batch_wide); for chain position c (ragged
  * index i = chain_off_d[b] + c): chain_state_d[i] = model state whose Gaussian it uses,
  * chain_band_d[d*total_chain + i] = log a(c-d -> c) (float32; 0.0 for the reference's
  * missing cross-word keys, -inf to forbid), chain_start_d[i] != 0 marks states initialised at
@@ -212,6 +218,15 @@ int lsr_decode_chain_batch(lsr_ctx* ctx, const float* feats_d, const int64_t* fr
                            const int32_t* chain_state_d, const float* chain_band_d,
                            const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d,
                            float* final_d);
+
+/* lsr_decode_chain_batch for chains of up to 127 states (e.g. the forced alignment of a 9-digit string:
+ * 75 states; hidden_markov_model.py:498-501 sizes its pointers for 127): two wavefronts per utterance,
+ * about half the speed per utterance.  No final_d output.  Chains outside 1..127 get score NaN. */
+int lsr_decode_chain_batch_wide(lsr_ctx* ctx, const float* feats_d, const int64_t* frame_off_d,
+                                int n_utts, int64_t total_frames, int max_frames,
+                                const int64_t* chain_off_d, int64_t total_chain,
+                                const int32_t* chain_state_d, const float* chain_band_d,
+                                const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d);
 
 /* The penalty sweep of scripts/project5_find_trans_ndigits_with_sil.py:71-88 (the same
  * utterances decoded once per candidate between-word log-probability) as one call: emission scores

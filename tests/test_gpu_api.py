@@ -91,13 +91,13 @@ def test_c_abi_rejects_bad_arguments():
     d = (ctypes.c_double * 4)()
     assert lib.lsr_model_upload(eng.ctx, 0, d, d, d) == -1
     assert lib.lsr_model_upload(eng.ctx, 5000, d, d, d) == -3
-    band = np.zeros((3, 70), np.float32)
+    band = np.zeros((3, 130), np.float32)
     lo = np.array([0], np.int32)
-    up = np.array([69], np.int32)
-    rc = lib.lsr_loop_graph_upload(eng.ctx, 70, 1, band.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+    up = np.array([129], np.int32)
+    rc = lib.lsr_loop_graph_upload(eng.ctx, 130, 1, band.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                    lo.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                    up.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), -1)
-    assert rc == -3 and b"64" in lib.lsr_last_error(eng.ctx)
+    assert rc == -3 and b"127" in lib.lsr_last_error(eng.ctx)
     assert lib.lsr_loop_set_between(eng.ctx, ctypes.c_double(float("nan")), 0) == -1
     assert lib.lsr_profile_get(eng.ctx, 99, None, None) == -1
     fresh = ctypes.c_void_p()
@@ -124,7 +124,8 @@ def test_c_abi_rejects_bad_arguments():
 
 
 def test_sixty_four_state_chain_and_limit():
-    """Largest supported alignment chain (64 positions) against the oracle; 65 is refused."""
+    """Largest one-wavefront alignment chain (64 positions) and the first two-wavefront sizes (72, 127) against the
+    oracle; 128 and more are refused (the reference's int8 pointers end at 127)."""
     from loe_speech_recognition_amd import HiddenMarkovModelMultiWord
 
     rng = np.random.default_rng(33)
@@ -150,7 +151,21 @@ def test_sixty_four_state_chain_and_limit():
     mu, U, ld = O.export_gaussians(gauss)
     s_ref, p_ref, _ = O.viterbi_chain_fast(O.emission_fast(x, mu, U, ld), O.band_from_ltp(ltp, 64))
     assert score == s_ref and np.array_equal(path, p_ref)
-    too_long = HiddenMarkovModelMultiWord.from_labels(chain + "aS", prod)
+    for longer in (chain + "aS", chain + "aSbSaSbSaSbSaScS"):          # 72 and 127 states
+        hmm = HiddenMarkovModelMultiWord.from_labels(longer, prod)
+        n = hmm.num_of_states
+        seq = np.concatenate([parts[c][0] for c in longer])
+        idx = np.minimum(np.arange(300) * n // 300, n - 1)
+        xl = (seq[idx] + 0.5 * rng.standard_normal((300, 39))).astype(np.float32)
+        ltp, gauss, _ = O.stack_models([O.WordModelRef(c, *parts[c]) for c in longer])
+        mu, U, ld = O.export_gaussians(gauss)
+        # a mixed batch: the long utterance, a short one, and the 64-state input again (all take the wide form)
+        got = hmm.predict_batch([xl, xl[:n + 3], xl[:150]])
+        for (score, path), xi in zip(got, (xl, xl[:n + 3], xl[:150])):
+            s_ref, p_ref, _ = O.viterbi_chain_fast(O.emission_fast(xi, mu, U, ld), O.band_from_ltp(ltp, n))
+            assert score == s_ref and np.array_equal(path, p_ref), n
+    assert n == 127
+    too_long = HiddenMarkovModelMultiWord.from_labels(chain + "aSbSaSbSaSbSaScSaS", prod)
     with pytest.raises(ValueError):
         too_long.predict(x)
 

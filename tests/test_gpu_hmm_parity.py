@@ -61,6 +61,49 @@ def test_g2_alignment_chain(tag):
         assert np.array_equal(path, g[f"{tag}_T{T}_path"])
 
 
+@pytest.mark.parametrize("tag", ["n75", "n123"])
+def test_g7_long_alignment_chain(tag):
+    """Forced-alignment chains of 75 and 123 states (two wavefronts per utterance) against the reference's output."""
+    from loe_speech_recognition_amd import HiddenMarkovModelMultiWord
+
+    g = load("hmm_g7_wide.npz")
+    words = {lab: word(g, f"chain_{lab}", lab) for lab in "123S"}
+    hmm = HiddenMarkovModelMultiWord.from_labels(str(g[f"{tag}_chain"]), words)
+    assert hmm.num_of_states == int(tag[1:])
+    xs = [g[f"{tag}_T{T}_x"] for T in (160, 300)]
+    for (score, path), T in zip(hmm.predict_batch(xs), (160, 300)):          # both in one batch
+        assert score == g[f"{tag}_T{T}_score"]
+        assert path.dtype == np.int8 and np.array_equal(path, g[f"{tag}_T{T}_path"])
+    score, path = hmm.predict(xs[0][:1])                                     # one frame: no back-pointer
+    assert path.tolist() == [-1]
+
+
+def test_g7_loop_of_123_states():
+    """Free word loop over 24 five-state words and silence (123 states, emission rows of 128 floats) against the
+    reference: scores, paths, label strings, for int, np.float64 and float penalties."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference
+
+    g = load("hmm_g7_wide.npz")
+    order = [str(x) for x in g["loop_order"]]
+    inf = HiddenMarkovModelInference.from_models([word(g, f"loop_{lab}", lab) for lab in order])
+    assert inf._model_boundaries.upper_boundaries[-1] == 122
+    n = int(g["n_utts"])
+    xs = [g[f"u{i}_x"] for i in range(n)]
+    for tag in ("m100", "dflt", "m3f"):
+        inf._log_transition_probability_between_words = BETWEEN[tag]
+        labels = inf.predict_batch(xs)
+        vit = inf.viterbi_batch(xs)
+        for i in range(n):
+            assert vit[i][0] == g[f"u{i}_{tag}_score"], (i, tag)
+            assert np.array_equal(vit[i][1], g[f"u{i}_{tag}_path"]), (i, tag)
+            assert labels[i] == str(g[f"u{i}_{tag}_labels"]), (i, tag)
+    # the narrow graph still decodes after the wide one used the context (tables and strides are re-uploaded)
+    g3 = load("hmm_g3_loop.npz")
+    small = loop_decoder(g3)
+    small._log_transition_probability_between_words = -100
+    assert small.predict(g3["u4_x"]) == str(g3["u4_m100_labels"])
+
+
 def test_g3_loop_decode():
     g = load("hmm_g3_loop.npz")
     inf = loop_decoder(g)

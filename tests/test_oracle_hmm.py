@@ -83,6 +83,39 @@ def test_g2_alignment_chain(golden_dir, tag):
     assert s_ref == s_fast and np.array_equal(p_ref, p_fast)
 
 
+@pytest.mark.parametrize("tag", ["n75", "n123"])
+def test_g7_long_alignment_chain(golden_dir, tag):
+    """Chains beyond 64 states (reference fixture): the restatement has no size limit of its own."""
+    g = load(golden_dir, "hmm_g7_wide.npz")
+    words = {lab: word(g, f"chain_{lab}") for lab in "123S"}
+    ltp, gauss, _ = O.stack_models([words[c] for c in str(g[f"{tag}_chain"])])
+    assert len(gauss) == int(tag[1:])
+    mu, U, ld = O.export_gaussians(gauss)
+    band = O.band_from_ltp(ltp, len(gauss))
+    for T in (160, 300):
+        score, path, _ = O.viterbi_chain_fast(O.emission_fast(g[f"{tag}_T{T}_x"], mu, U, ld), band)
+        assert score == g[f"{tag}_T{T}_score"] and np.array_equal(path, g[f"{tag}_T{T}_path"])
+
+
+def test_g7_loop_of_123_states(golden_dir):
+    g = load(golden_dir, "hmm_g7_wide.npz")
+    order = [str(x) for x in g["loop_order"]]
+    words = [word(g, f"loop_{lab}") for lab in order]
+    for w, lab in zip(words, order):
+        w.label = lab
+    ltp, gauss, bounds = O.stack_models(words)
+    assert bounds.num_states == 123
+    mu, U, ld = O.export_gaussians(gauss)
+    band = O.band_from_ltp(ltp, 123, [bounds.find_lower(s) for s in range(123)])
+    for i in range(int(g["n_utts"])):
+        emis = O.emission_fast(g[f"u{i}_x"], mu, U, ld)
+        for tag in ("m100", "dflt", "m3f"):
+            score, path = O.viterbi_loop_fast(emis, band, bounds.lower, bounds.upper, BETWEEN[tag])
+            assert score == g[f"u{i}_{tag}_score"], (i, tag)
+            assert np.array_equal(path, g[f"u{i}_{tag}_path"]), (i, tag)
+            assert "".join(bounds.get_labels(path)) == str(g[f"u{i}_{tag}_labels"])
+
+
 def loop_setup(g):
     words = [word(g, lab) for lab in LOOP_LABELS]
     ltp, gauss, bounds = O.stack_models(words)

@@ -267,12 +267,75 @@ def g6_collection(rng):
     np.savez_compressed(os.path.join(OUT, "hmm_g6_collection.npz"), **out)
 
 
+def g7_wide(rng):
+    """Graphs beyond 64 states (the int8 back-pointers of hidden_markov_model.py:498-501 reach 127): forced-alignment
+    chains of 75 and 123 states and a free word loop over 24 five-state words plus silence (123 states)."""
+    out = {}
+    words = {}
+    for lab in "123S":
+        words[lab] = random_word(rng, 3 if lab == "S" else 5)
+        out[f"chain_{lab}_means"], out[f"chain_{lab}_cov"], out[f"chain_{lab}_trans"] = words[lab]
+    trainables = {lab: make_trainable(lab, *words[lab]) for lab in words}
+    for digits, tag in (("123123123", "n75"), ("312213321123231", "n123")):
+        chain = "S" + "".join(c + "S" for c in digits)
+        hmm = H.HiddenMarkovModelMultiWord.from_labels(chain, trainables)
+        all_means = np.concatenate([words[c][0] for c in chain])
+        assert all_means.shape[0] == int(tag[1:])
+        out[f"{tag}_chain"] = np.array(chain)
+        for T in (160, 300):
+            x = sample_utt(rng, all_means, T)
+            score, path = hmm.predict(x)
+            assert path.dtype == np.int8 and path.max() > 64
+            out[f"{tag}_T{T}_x"], out[f"{tag}_T{T}_score"], out[f"{tag}_T{T}_path"] = x, np.float32(score), path
+    labels = [chr(ord("a") + i) for i in range(24)]
+    order = sorted(labels + ["S"])                                  # "S" sorts before the lower-case names
+    loop_words = {lab: random_word(rng, 3 if lab == "S" else 5) for lab in order}
+    loop_words["q"] = tuple(a.copy() for a in loop_words["c"])      # identical words on both sides of state 64: ties
+    inf = H.HiddenMarkovModelInference()
+    ltp = H.LogTransitionProbabilities()
+    mvn = []
+    mb = MB.ModelBoundary()
+    for lab in order:
+        m = make_trainable(lab, *loop_words[lab])
+        out[f"loop_{lab}_means"], out[f"loop_{lab}_cov"], out[f"loop_{lab}_trans"] = loop_words[lab]
+        ltp.append(m._log_transition_probs)
+        mvn.extend(m._multivariate_normals)
+        mb.append(m.num_of_states)
+    mb.add_model_labels(list(order))
+    inf._log_transition_probs, inf._multivariate_normals, inf._model_boundaries = ltp, mvn, mb
+    assert mb.upper_boundaries[-1] == 122
+    out["loop_order"] = np.array(order)
+    utts = []
+    for text in ("a", "x", "qc", "SbS", "mnop", "wSxSw", "abcxwvq", "cq"):
+        seq = np.concatenate([loop_words[c][0] for c in text])
+        utts.append(sample_utt(rng, seq, max(12, 13 * len(text) + int(rng.integers(0, 9)))))
+    utts.append((rng.standard_normal((25, D)) * 3).astype(np.float32))
+    for i, x in enumerate(utts):
+        out[f"u{i}_x"] = x
+        for tag, between in (("m100", -100), ("dflt", np.log(0.005)), ("m3f", -3.0)):
+            inf._log_transition_probability_between_words = between
+            score, path = inf._viterbi(observation_sequence=x)
+            out[f"u{i}_{tag}_score"], out[f"u{i}_{tag}_path"] = np.float32(score), path
+            out[f"u{i}_{tag}_labels"] = np.array(inf.predict(x))
+    out["n_utts"] = np.int64(len(utts))
+    np.savez_compressed(os.path.join(OUT, "hmm_g7_wide.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    g1_emission(np.random.default_rng(101))
-    g2_single(np.random.default_rng(102))
-    g3_loop(np.random.default_rng(103))
-    g4_labels()
-    g5_training(np.random.default_rng(105))
-    g6_collection(np.random.default_rng(106))
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]      # every set has its own seed
+    if "g1" in which:
+        g1_emission(np.random.default_rng(101))
+    if "g2" in which:
+        g2_single(np.random.default_rng(102))
+    if "g3" in which:
+        g3_loop(np.random.default_rng(103))
+    if "g4" in which:
+        g4_labels()
+    if "g5" in which:
+        g5_training(np.random.default_rng(105))
+    if "g6" in which:
+        g6_collection(np.random.default_rng(106))
+    if "g7" in which:
+        g7_wide(np.random.default_rng(107))
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("hmm_")))
