@@ -12,9 +12,10 @@
 //   the transform to complex64); magnitude, power and everything after are float32.
 //   The 40 mel energies go to a [frame][40] scratch array and the utterance maximum is kept
 //   with atomicMax on the (non-negative) float bit pattern.
-// Kernel 3 (finish): one workgroup per 64 frames (+8 frames halo each side): dB with the
-//   utterance maximum as reference and the -80 dB floor, DCT, deltas (edge frames repeat the
-//   polynomial fit of the first/last full window), normalisation, coalesced store.
+// Kernel 3 (finish): one workgroup per 128 frames (+8 frames halo each side): dB with the
+//   utterance maximum as reference and the -80 dB floor, DCT (float64 on the matrix unit), deltas
+//   (edge frames repeat the polynomial fit of the first/last full window), normalisation,
+//   coalesced store.
 #include "lsr_internal.h"
 
 struct cplx {
@@ -340,23 +341,30 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, out_m, out_max, out_utt);
 }
 
-#define FN_FRAMES 64
+#define FN_FRAMES 128
 #define FN_HALO 8
-#define FN_STAGED (FN_FRAMES + 2 * FN_HALO)
+#define FN_STAGED (FN_FRAMES + 2 * FN_HALO)      // 144 = 9 tiles of 16 frames
 #define FN_MEL_STRIDE 44
-#define FN_DCT_GROUPS (256 / LSR_N_MFCC)
+#define FN_CEPS_LD 14
+
+typedef double fn_v4d __attribute__((ext_vector_type(4)));
+
+// 10 log10(x) for x >= 1e-10 as log2(x) * 10 log10(2): one hardware logarithm and one multiply, within 2 ulp of
+// the float32 result NumPy computes (the tolerance of the features is four orders of magnitude wider)
+__device__ __forceinline__ float fn_db(float x) { return log2f(x) * 3.01029995663981195f; }
 
 __global__ __launch_bounds__(256) void lsr_mfcc_finish_kernel(
     const float* __restrict__ mel, const unsigned int* __restrict__ uttmax, const int64_t* __restrict__ frame_off,
     const int32_t* __restrict__ frame_utt, int64_t total_frames, const double* __restrict__ dct,
     float* __restrict__ feats) {
-    // rows of 44 floats: 16-byte aligned for 128-bit reads, and the rows a wavefront reads at once
-    // (five consecutive frames) start on different banks
+    // rows of 44 floats: 16-byte aligned for 128-bit accesses.  The log-mel tile is dead once the cepstra exist;
+    // the output staging area reuses its memory.
     __shared__ __attribute__((aligned(16))) float logmel[FN_STAGED][FN_MEL_STRIDE];
-    __shared__ float ceps[FN_STAGED][LSR_N_MFCC];
-    __shared__ float outb[FN_FRAMES][LSR_DIM];
+    __shared__ float ceps[FN_STAGED][FN_CEPS_LD];
     __shared__ float refdb[FN_STAGED];
     __shared__ int pos_t[FN_FRAMES], len_t[FN_FRAMES];     // frame's index in its utterance, utterance length
+    float(*outb)[LSR_DIM] = (float(*)[LSR_DIM]) & logmel[0][0];            // [FN_FRAMES][39] <= the log-mel tile
+    static_assert(sizeof(float) * FN_FRAMES * LSR_DIM <= sizeof(float) * FN_STAGED * FN_MEL_STRIDE, "staging fits");
 
     const int tid = threadIdx.x;
     const int64_t g0 = (int64_t)blockIdx.x * FN_FRAMES;
@@ -373,11 +381,13 @@ __global__ __launch_bounds__(256) void lsr_mfcc_finish_kernel(
         g = g < 0 ? 0 : (g >= total_frames ? total_frames - 1 : g);
         mv[u] = *(const float4*)(mel + g * LSR_N_MELS + e % LSR_N_MELS);
     }
-    // thread (k, j) of the DCT below keeps row k of the DCT matrix in registers
-    const int dk = tid % LSR_N_MFCC, dj = tid / LSR_N_MFCC;
-    double drow[LSR_N_MELS];
+    // B operands of the DCT product below: lane (k-group kg = lane >> 4, column n = lane & 15) holds
+    // dct[n][4 ks + kg] for the ten k-steps (zero for the three unused columns)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int kg = lane >> 4, col = lane & 15;
+    double bop[LSR_N_MELS / 4];
 #pragma unroll
-    for (int n = 0; n < LSR_N_MELS; ++n) drow[n] = dct[dk * LSR_N_MELS + n];
+    for (int ks = 0; ks < LSR_N_MELS / 4; ++ks) bop[ks] = col < LSR_N_MFCC ? dct[col * LSR_N_MELS + 4 * ks + kg] : 0.0;
 
     // power_to_db(ref=max, amin=1e-10, top_db=80): the utterance maximum maps to exactly 0 dB,
     // so the floor is the constant -80
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(256) void lsr_mfcc_finish_kernel(
         float r = 0.f;
         if (g >= 0 && g < total_frames) {
             const int b = frame_utt[g];
-            r = 10.0f * log10f(fmaxf(1e-10f, __uint_as_float(uttmax[b])));
+            r = fn_db(fmaxf(1e-10f, __uint_as_float(uttmax[b])));
             const int fo = tid - FN_HALO;
             if (fo >= 0 && fo < FN_FRAMES) {
                 const int64_t lo = frame_off[b];
@@ -406,31 +416,30 @@ __global__ __launch_bounds__(256) void lsr_mfcc_finish_kernel(
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g >= 0 && g < total_frames) {
                 const float r = refdb[fr];
-                v.x = fmaxf(10.0f * log10f(fmaxf(1e-10f, mv[u].x)) - r, -80.0f);
-                v.y = fmaxf(10.0f * log10f(fmaxf(1e-10f, mv[u].y)) - r, -80.0f);
-                v.z = fmaxf(10.0f * log10f(fmaxf(1e-10f, mv[u].z)) - r, -80.0f);
-                v.w = fmaxf(10.0f * log10f(fmaxf(1e-10f, mv[u].w)) - r, -80.0f);
+                v.x = fmaxf(fn_db(fmaxf(1e-10f, mv[u].x)) - r, -80.0f);
+                v.y = fmaxf(fn_db(fmaxf(1e-10f, mv[u].y)) - r, -80.0f);
+                v.z = fmaxf(fn_db(fmaxf(1e-10f, mv[u].z)) - r, -80.0f);
+                v.w = fmaxf(fn_db(fmaxf(1e-10f, mv[u].w)) - r, -80.0f);
             }
             *(float4*)&logmel[fr][band] = v;
         }
     }
     __syncthreads();
 
-    // DCT-II: thread (k, j) produces coefficient k of frames j, j + 19, ...; the 13 threads of a
-    // frame read the same log-mel row (LDS broadcast)
-    if (dj < FN_DCT_GROUPS) {
-        for (int fr = dj; fr < FN_STAGED; fr += FN_DCT_GROUPS) {
-            const float4* row = (const float4*)logmel[fr];
-            double acc = 0.0;
+    // DCT-II on the float64 matrix unit: cepstra[16 frames][13] = logmel[16 frames][40] . dct^T, ten
+    // v_mfma_f64_16x16x4_f64 per tile of 16 frames (A: lane (kg, m) supplies logmel[frame m][4 ks + kg]; the result
+    // register r of lane (kg, n) is coefficient n of frame 4 r + kg).  The wavefronts take the nine tiles in turn.
+    for (int tile = wave; tile < FN_STAGED / 16; tile += 4) {
+        const float* arow = &logmel[tile * 16 + col][kg];
+        double aop[LSR_N_MELS / 4];
 #pragma unroll
-            for (int n4 = 0; n4 < LSR_N_MELS / 4; ++n4) {
-                const float4 v = row[n4];
-                acc = fma(drow[4 * n4], (double)v.x, acc);
-                acc = fma(drow[4 * n4 + 1], (double)v.y, acc);
-                acc = fma(drow[4 * n4 + 2], (double)v.z, acc);
-                acc = fma(drow[4 * n4 + 3], (double)v.w, acc);
-            }
-            ceps[fr][dk] = (float)acc;
+        for (int ks = 0; ks < LSR_N_MELS / 4; ++ks) aop[ks] = (double)arow[4 * ks];
+        fn_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < LSR_N_MELS / 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ks], bop[ks], acc, 0, 0, 0);
+        if (col < LSR_N_MFCC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ceps[tile * 16 + 4 * r + kg][col] = (float)acc[r];
         }
     }
     __syncthreads();
