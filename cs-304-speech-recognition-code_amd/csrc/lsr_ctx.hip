@@ -167,24 +167,19 @@ static int upload(lsr_ctx* ctx, T** dst, const T* src, size_t n, const char* wha
 }
 
 int lsr_frontend_init(lsr_ctx* ctx) {
-    std::vector<double> win(LSR_N_FFT), tw160(16 * 10 * 2), tw320(LSR_N_BINS * 2), dct(LSR_N_MFCC * LSR_N_MELS);
+    std::vector<double> win(LSR_N_FFT), tw_stage(11 * 16 * 2), dct(LSR_N_MFCC * LSR_N_MELS);
     std::vector<float> melw(LSR_N_MELS * LSR_N_BINS);
     std::vector<float> slot_w(64 * 6, 0.f);
     std::vector<int> slot_info(64, 0), band_slots(LSR_N_MELS * 2, 0);
     lsr_host_hann_window(win.data());
     lsr_host_mel_filterbank(melw.data());
     lsr_host_dct_matrix(dct.data());
-    for (int n2 = 0; n2 < 16; ++n2)
-        for (int k1 = 0; k1 < 10; ++k1) {
-            const double ang = -2.0 * M_PI * (double)(n2 * k1) / 160.0;
-            tw160[(n2 * 10 + k1) * 2 + 0] = cos(ang);
-            tw160[(n2 * 10 + k1) * 2 + 1] = sin(ang);
+    for (int k1 = 0; k1 < 11; ++k1)
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const double ang = -2.0 * M_PI * (double)(n2 * k1) / 320.0;
+            tw_stage[(k1 * 16 + n2) * 2 + 0] = cos(ang);
+            tw_stage[(k1 * 16 + n2) * 2 + 1] = sin(ang);
         }
-    for (int k = 0; k < LSR_N_BINS; ++k) {
-        const double ang = -2.0 * M_PI * (double)k / 320.0;
-        tw320[k * 2 + 0] = cos(ang);
-        tw320[k * 2 + 1] = sin(ang);
-    }
     // The non-zero weights of a band are one run of consecutive bins; cut every run into slots of
     // at most 6 bins.  The kernel gives one lane to each slot, so there must be at most 64.
     int n_slots = 0;
@@ -210,8 +205,7 @@ int lsr_frontend_init(lsr_ctx* ctx) {
     }
     int rc;
     if ((rc = upload(ctx, &ctx->d_window, win.data(), win.size(), "window"))) return rc;
-    if ((rc = upload(ctx, &ctx->d_tw160, tw160.data(), tw160.size(), "twiddles"))) return rc;
-    if ((rc = upload(ctx, &ctx->d_tw320, tw320.data(), tw320.size(), "twiddles"))) return rc;
+    if ((rc = upload(ctx, &ctx->d_tw_stage, tw_stage.data(), tw_stage.size(), "twiddles"))) return rc;
     if ((rc = upload(ctx, &ctx->d_slot_w, slot_w.data(), slot_w.size(), "mel slot weights"))) return rc;
     if ((rc = upload(ctx, &ctx->d_slot_info, slot_info.data(), slot_info.size(), "mel slots"))) return rc;
     if ((rc = upload(ctx, &ctx->d_band_slots, band_slots.data(), band_slots.size(), "mel bands"))) return rc;
@@ -225,8 +219,7 @@ static void free_ptr(void* p) {
 
 void lsr_frontend_free(lsr_ctx* ctx) {
     free_ptr(ctx->d_window);
-    free_ptr(ctx->d_tw160);
-    free_ptr(ctx->d_tw320);
+    free_ptr(ctx->d_tw_stage);
     free_ptr(ctx->d_slot_w);
     free_ptr(ctx->d_slot_info);
     free_ptr(ctx->d_band_slots);

@@ -28,8 +28,7 @@ struct lsr_ctx {
 
     // front-end tables (device)
     double* d_window = nullptr;      // [320]
-    double* d_tw160 = nullptr;       // [16][10][2]  W160^(n2*k1)
-    double* d_tw320 = nullptr;       // [161][2]     W320^k
+    double* d_tw_stage = nullptr;    // [11][16][2]  W320^(n2 k1): twiddles between the two FFT stages
     float* d_slot_w = nullptr;       // [64][6] mel weights of each slot (a run of <= 6 bins of one band)
     int* d_slot_info = nullptr;      // [64] first bin of each slot
     int* d_band_slots = nullptr;     // [40][2] first slot and slot count of each band

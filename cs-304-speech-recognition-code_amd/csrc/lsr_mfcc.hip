@@ -4,14 +4,15 @@
 // Savitzky-Golay deltas of width 9 -> per-frame z-normalisation of the statics).
 //
 // Kernel 1 (frame index): utterance id of every frame of the ragged batch.
-// Kernel 2 (mel power):  one 256-thread workgroup per 16 frames.  The 320-point real FFT is
-//   a 160-point complex FFT of (even, odd) sample pairs, factored 10 x 16: 16 lanes per frame
-//   each do a 10-point DFT in registers, the data is transposed through LDS, 10 lanes per
-//   frame each do a 16-point DFT, and the real spectrum is untangled from Z[k], Z[160-k].
-//   Window product and FFT are float64 (librosa multiplies by a float64 window and rounds
-//   the transform to complex64); magnitude, power and everything after are float32.
-//   The 40 mel energies go to a [frame][40] scratch array and the utterance maximum is kept
-//   with atomicMax on the (non-negative) float bit pattern.
+// Kernel 2 (mel power): persistent single-wavefront workgroups, four frames per pass.  The 320-point real
+//   FFT is factored 20 x 16 on the real samples n = 16 n1 + n2: 16 lanes per frame each do a 20-point DFT of
+//   real input in registers (three radix steps 5, 2, 2; only the outputs k1 = 0..10 are needed, the others are
+//   their conjugates), the twiddled results cross LDS once, and 11 lanes per frame each do a 16-point complex
+//   DFT whose sixteen outputs are, as they stand or conjugated, sixteen of the bins 0..160 - there is no
+//   separate pass that untangles a half-size complex transform.  Window product and FFT are float64 (librosa
+//   multiplies by a float64 window and rounds the transform to complex64); magnitude, power and everything
+//   after are float32.  The 40 mel energies go to a [frame][40] scratch array and the utterance maximum is
+//   kept with atomicMax on the (non-negative) float bit pattern.
 // Kernel 3 (finish): one workgroup per 128 frames (+8 frames halo each side): dB with the
 //   utterance maximum as reference and the -80 dB floor, DCT (float64 on the matrix unit), deltas
 //   (edge frames repeat the polynomial fit of the first/last full window), normalisation,
@@ -77,8 +78,8 @@ __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, co
 }
 
 #define MP_FRAMES 4          // frames per wavefront pass
+#define MP_K1 11             // outputs kept of a 20-point real DFT (k1 = 0..10)
 #define MP_YLD 17            // complex elements per (frame, k1) row: 16 + 1 pad
-#define MP_ZLD 161
 #define MP_PLD 164
 #define MP_SLOT_BINS 6       // bins per mel slot (61 slots cover the 260 non-zero weights)
 
@@ -90,26 +91,21 @@ __device__ __forceinline__ int4 mp_load_info(const int4* __restrict__ frame_info
     return r;
 }
 
-// samples 2m, 2m+1 (m = 16 n1 + n2, n1 = 0..9) of the frame described by `info` for one lane; zero
-// outside the clip
+// samples 16 n1 + n2 (n1 = 0..19) of the frame described by `info` for one lane; zero outside the clip
 template <typename SAMPLE>
 __device__ __forceinline__ void mp_load_samples(const SAMPLE* __restrict__ audio, const int4 info, int n2,
                                                 float (&xs)[20]) {
     const int lo = info.w & 0xffff, hi = (int)((unsigned)info.w >> 16);
     const int64_t start = (int64_t)(((uint64_t)(uint32_t)info.y << 32) | (uint32_t)info.x);
-    const SAMPLE* sig = audio + start + 2 * n2;
+    const SAMPLE* sig = audio + start + n2;
     if (lo == 0 && hi == LSR_N_FFT) {
 #pragma unroll
-        for (int n1 = 0; n1 < 10; ++n1) {
-            xs[2 * n1] = (float)sig[32 * n1];
-            xs[2 * n1 + 1] = (float)sig[32 * n1 + 1];
-        }
+        for (int n1 = 0; n1 < 20; ++n1) xs[n1] = (float)sig[16 * n1];
     } else {
 #pragma unroll
-        for (int n1 = 0; n1 < 10; ++n1) {
-            const int i0 = 2 * n2 + 32 * n1, i1 = i0 + 1;
-            xs[2 * n1] = (i0 >= lo && i0 < hi) ? (float)sig[32 * n1] : 0.f;
-            xs[2 * n1 + 1] = (i1 >= lo && i1 < hi) ? (float)sig[32 * n1 + 1] : 0.f;
+        for (int n1 = 0; n1 < 20; ++n1) {
+            const int i = n2 + 16 * n1;
+            xs[n1] = (i >= lo && i < hi) ? (float)sig[16 * n1] : 0.f;
         }
     }
 }
@@ -122,15 +118,33 @@ __device__ __forceinline__ float mp_power(double re64, double im64) {
     return fmaf(re, re, im * im);
 }
 
-// untangle one bin pair (k, 160-k) of a frame from the half-size transform Z:
-// Z = Xe + i Xo (spectra of the even/odd samples), Xe = (Z[k] + conj Z[160-k]) / 2,
-// Xo = -i (Z[k] - conj Z[160-k]) / 2, X[k] = Xe + W320^k Xo, X[160-k] = conj(Xe - W320^k Xo)
-__device__ __forceinline__ void mp_untangle(const cplx zk, const cplx zm, float* __restrict__ pw, int k, cplx w) {
-    const cplx e = {0.5 * (zk.re + zm.re), 0.5 * (zk.im - zm.im)};
-    const cplx d = {0.5 * (zk.re - zm.re), 0.5 * (zk.im + zm.im)};
-    const cplx t = cmul(cmul_negi(d), w);
-    pw[k] = mp_power(e.re + t.re, e.im + t.im);
-    if (k != 80) pw[160 - k] = mp_power(e.re - t.re, e.im - t.im);
+// 5-point DFT of real samples: X0 (real), X1, X2; X3 = conj X2, X4 = conj X1
+__device__ __forceinline__ void rdft5(double x0, double x1, double x2, double x3, double x4, double& X0, cplx& X1,
+                                      cplx& X2) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;   // cos(2pi/5), cos(4pi/5)
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;    // sin(2pi/5), sin(4pi/5)
+    const double t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+    X0 = x0 + t1 + t2;
+    X1 = {fma(c2, t2, fma(c1, t1, x0)), fma(-s2, t4, -s1 * t3)};
+    X2 = {fma(c1, t2, fma(c2, t1, x0)), fma(s1, t4, -s2 * t3)};
+}
+
+// 10-point DFT of real samples from the 5-point DFTs of its even (A) and odd (B) samples: E[0..5], E0 and E5 real
+struct rspec10 {
+    double e0, e5;
+    cplx e1, e2, e3, e4;
+};
+__device__ __forceinline__ rspec10 rdft10(double a0, cplx a1, cplx a2, double b0, cplx b1, cplx b2) {
+    rspec10 r;
+    r.e0 = a0 + b0;
+    r.e5 = a0 - b0;
+    const cplx t1 = cmul(b1, cplx{0.80901699437494742410, -0.58778525229247312917});      // W10^1
+    const cplx t2 = cmul(b2, cplx{0.30901699437494742410, -0.95105651629515357212});      // W10^2
+    r.e1 = cadd(a1, t1);
+    r.e4 = {a1.re - t1.re, t1.im - a1.im};                // conj(a1 - t1)
+    r.e2 = cadd(a2, t2);
+    r.e3 = {a2.re - t2.re, t2.im - a2.im};
+    return r;
 }
 
 // one pass's results: lane = band writes its energy of each frame (a coalesced row per frame), lanes 0..3
@@ -149,36 +163,34 @@ __device__ __forceinline__ void mp_store_pass(float* __restrict__ mel, unsigned 
 template <typename SAMPLE>
 __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     const SAMPLE* __restrict__ audio, const int4* __restrict__ frame_info, int64_t total_frames, int64_t n_groups,
-    const double* __restrict__ window,
-    const double* __restrict__ tw160, const double* __restrict__ tw320, const float* __restrict__ slot_w,
+    const double* __restrict__ window, const double* __restrict__ tw_stage, const float* __restrict__ slot_w,
     const int* __restrict__ slot_info, const int* __restrict__ band_slots, float* __restrict__ mel,
     unsigned int* __restrict__ uttmax) {
-    __shared__ __attribute__((aligned(16))) cplx buf[MP_FRAMES * 10 * MP_YLD];   // Y, then reused as Z [4][161]
+    __shared__ __attribute__((aligned(16))) cplx buf[MP_FRAMES * MP_K1 * MP_YLD];   // Y[frame][k1][n2], twiddled
     __shared__ float power[MP_FRAMES][MP_PLD];
-    __shared__ float part[MP_FRAMES][64];
     __shared__ int band_s[2 * LSR_N_MELS];                      // first slot and slot count of each band
-    __shared__ __attribute__((aligned(16))) cplx win_s[160];     // window pairs (w[2m], w[2m+1])
-    __shared__ __attribute__((aligned(16))) cplx tw_s[10 * 16];  // W160^(n2 k1) as [k1][n2]
+    __shared__ __attribute__((aligned(16))) cplx win_s[160];     // window pairs (w[16 (2j) + n2], w[16 (2j + 1) + n2])
+    __shared__ __attribute__((aligned(16))) cplx tw_s[10 * 16];  // W320^(n2 k1) as [k1 - 1][n2], k1 = 1..10
+    float(*part)[64] = (float(*)[64])buf;                       // slot sums of the filterbank: the transform buffer is free by then
 
     const int lane = threadIdx.x;
     const int f = lane >> 4, n2 = lane & 15;
 
-    // tables of the first two stages live in LDS (read as 16-byte pairs, one bank row per 16 lanes)
+    // tables of the first stage live in LDS (read as 16-byte pairs, one bank row per 16 lanes)
     for (int i = lane; i < 160; i += 64) {
-        win_s[i] = {window[2 * i], window[2 * i + 1]};
-        const int k1 = i >> 4, m = i & 15;
-        tw_s[i] = {tw160[m * 20 + 2 * k1], tw160[m * 20 + 2 * k1 + 1]};
+        const int j = i >> 4, m = i & 15;
+        win_s[i] = {window[16 * (2 * j) + m], window[16 * (2 * j + 1) + m]};
+        tw_s[i] = {tw_stage[2 * (16 * (j + 1) + m)], tw_stage[2 * (16 * (j + 1) + m) + 1]};
     }
     for (int i = lane; i < 2 * LSR_N_MELS; i += 64) band_s[i] = band_slots[i];
-    // per-lane constants kept in registers across the grid-stride loop
-    const cplx tw_a = {tw320[2 * lane], tw320[2 * lane + 1]};                          // bin pair k = lane
-    const cplx tw_b = {tw320[2 * (64 + n2)], tw320[2 * (64 + n2) + 1]};                // bin pair k = 64 + (lane & 15)
-    const cplx tw_c = {tw320[160], tw320[161]};                                        // bin 80
-    // mel filterbank slot of this lane: up to MP_SLOT_BINS consecutive bins of one band
+    // mel filterbank slot of this lane: up to MP_SLOT_BINS consecutive bins of one band (weights in registers)
     float sw[MP_SLOT_BINS];
 #pragma unroll
     for (int j = 0; j < MP_SLOT_BINS; ++j) sw[j] = slot_w[lane * MP_SLOT_BINS + j];
     const int slot_start = slot_info[lane];
+    // second stage: lane = (frame, k1) for the first 44 lanes
+    const int fb = lane / MP_K1, kb = lane - fb * MP_K1;
+    const bool live_b = lane < MP_FRAMES * MP_K1;
     // software pipeline over the grid-stride loop: samples one group ahead, frame records two ahead,
     // so no load is waited for in the iteration that issues it
     float xs[20];
@@ -199,100 +211,103 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
         const int64_t g0 = grp * MP_FRAMES;
         const int utt_cur = info_cur.z;
 
-        // ---- stage A: 10-point DFTs over n1 for fixed (frame, n2) ------------------------------
+        // ---- stage A: 20-point DFT of the REAL windowed samples 16 n1 + n2 for fixed (frame, n2); the outputs
+        // k1 = 0..10 (the rest are their conjugates) times W320^(n2 k1) go to the transform buffer -------------
         {
             // window pairs and stage twiddles: all twenty LDS reads are in flight before the first use
             cplx wv[10], tv[10];
 #pragma unroll
-            for (int n1 = 0; n1 < 10; ++n1) wv[n1] = win_s[16 * n1 + n2];
+            for (int j = 0; j < 10; ++j) wv[j] = win_s[16 * j + n2];
 #pragma unroll
             for (int k = 0; k < 10; ++k) tv[k] = tw_s[16 * k + n2];
-            cplx z[10];
+            double z[20];
 #pragma unroll
-            for (int n1 = 0; n1 < 10; ++n1)
-                z[n1] = {wv[n1].re * (double)xs[2 * n1], wv[n1].im * (double)xs[2 * n1 + 1]};
+            for (int j = 0; j < 10; ++j) {
+                z[2 * j] = wv[j].re * (double)xs[2 * j];
+                z[2 * j + 1] = wv[j].im * (double)xs[2 * j + 1];
+            }
             // The next group's samples travel while this group is transformed.  The loads must be issued
             // after the last read of the current samples: the memory counter is in-order, so a read of
             // `xs` placed after them would wait for the new loads as well.  The empty asm statements pin
             // that order (the products are complete, then the loads start).
 #pragma unroll
-            for (int n1 = 0; n1 < 10; ++n1) asm volatile("" : "+v"(z[n1].re), "+v"(z[n1].im));
+            for (int n1 = 0; n1 < 20; ++n1) asm volatile("" : "+v"(z[n1]));
             asm volatile("" ::: "memory");
             if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, out_m, out_max, out_utt);
             mp_load_samples(audio, info_nxt, n2, xs);
             info_cur = info_nxt;
             info_nxt = mp_load_info(frame_info, total_frames, (grp + 2 * (int64_t)gridDim.x) * MP_FRAMES + f);
-            cplx E[5], O[5];
-            dft5(z[0], z[2], z[4], z[6], z[8], E);
-            dft5(z[1], z[3], z[5], z[7], z[9], O);
-            // W10^k, k = 0..4
-            const double wc[5] = {1.0, 0.80901699437494742410, 0.30901699437494742410, -0.30901699437494742410,
-                                  -0.80901699437494742410};
-            const double wsn[5] = {0.0, -0.58778525229247312917, -0.95105651629515357212, -0.95105651629515357212,
-                                   -0.58778525229247312917};
+            // samples 4 c + r, r = 0..3: four 5-point DFTs, two 10-point combinations (even / odd samples), one 20-point
+            double a0, b0;
+            cplx a1, a2, b1, b2;
+            rdft5(z[0], z[4], z[8], z[12], z[16], a0, a1, a2);
+            rdft5(z[2], z[6], z[10], z[14], z[18], b0, b1, b2);
+            const rspec10 E = rdft10(a0, a1, a2, b0, b1, b2);
+            rdft5(z[1], z[5], z[9], z[13], z[17], a0, a1, a2);
+            rdft5(z[3], z[7], z[11], z[15], z[19], b0, b1, b2);
+            const rspec10 O = rdft10(a0, a1, a2, b0, b1, b2);
+            cplx* col = buf + (f * MP_K1) * MP_YLD + n2;
+            // Y[k] = E[k] + W20^k O[k], Y[10 - k] = conj(E[k] - W20^k O[k]); Y0, Y10 real, Y5 = E5 - i O5
+            col[0] = {E.e0 + O.e0, 0.0};
+            {
+                const double y10 = E.e0 - O.e0;
+                col[10 * MP_YLD] = {y10 * tv[9].re, y10 * tv[9].im};
+            }
+            col[5 * MP_YLD] = cmul(cplx{E.e5, -O.e5}, tv[4]);
+            const cplx ek[4] = {E.e1, E.e2, E.e3, E.e4}, ok[4] = {O.e1, O.e2, O.e3, O.e4};
+            const double wc[4] = {0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917,
+                                  0.30901699437494742410};                                      // cos(k pi / 10)
+            const double ws[4] = {-0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410,
+                                  -0.95105651629515357212};                                     // -sin(k pi / 10)
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const cplx wo = cmul(O[k], cplx{wc[k], wsn[k]});
-                buf[(f * 10 + k) * MP_YLD + n2] = cmul(cadd(E[k], wo), tv[k]);
-                buf[(f * 10 + k + 5) * MP_YLD + n2] = cmul(csub(E[k], wo), tv[k + 5]);
+            for (int k = 1; k <= 4; ++k) {
+                const cplx t = cmul(ok[k - 1], cplx{wc[k - 1], ws[k - 1]});
+                col[k * MP_YLD] = cmul(cadd(ek[k - 1], t), tv[k - 1]);
+                col[(10 - k) * MP_YLD] = cmul(cplx{ek[k - 1].re - t.re, t.im - ek[k - 1].im}, tv[9 - k]);
             }
         }
         __syncthreads();
 
-        // ---- stage B: 16-point DFTs over n2 for fixed (frame, k1) -------------------------------
-        {
+        // ---- stage B: 16-point DFTs over n2 for fixed (frame, k1): X[k1 + 20 q], q = 0..15.  Bins up to 160 are
+        // wanted: q <= 7 directly (and q = 8 for k1 = 0), the other outputs are the conjugates of the bins
+        // 320 - 20 q - k1 (for k1 = 0 and k1 = 10 those repeat bins the lane already has).  The power goes straight
+        // to the power table: no second pass over the spectrum -----------------------------------------------
+        if (live_b) {
             cplx y[16];
-            const bool live = lane < MP_FRAMES * 10;
-            if (live) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) y[i] = buf[lane * MP_YLD + i];
-            }
-            __syncthreads();                 // every Y row is in registers: the buffer becomes Z
-            if (live) {
-                const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178;   // cos, sin(pi/8)
-                const double R = 0.70710678118654752440;
-                // W16^m = (cos(pi m/8), -sin(pi m/8)) for m = 1,2,3,4,6,9
-                const cplx w1 = {C1, -S1}, w2 = {R, -R}, w3 = {S1, -C1}, w6 = {-R, -R}, w9 = {-C1, S1};
-                cplx u[4][4];                // u[n2][k1] = DFT4 over n1 of y[4 n1 + n2]
+            for (int i = 0; i < 16; ++i) y[i] = buf[lane * MP_YLD + i];
+            const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178;   // cos, sin(pi/8)
+            const double R = 0.70710678118654752440;
+            // W16^m = (cos(pi m/8), -sin(pi m/8)) for m = 1,2,3,4,6,9
+            const cplx w1 = {C1, -S1}, w2 = {R, -R}, w3 = {S1, -C1}, w6 = {-R, -R}, w9 = {-C1, S1};
+            cplx u[4][4];                // u[n2][k1] = DFT4 over n1 of y[4 n1 + n2]
 #pragma unroll
-                for (int m = 0; m < 4; ++m) dft4(y[m], y[4 + m], y[8 + m], y[12 + m], u[m]);
-                u[1][1] = cmul(u[1][1], w1);
-                u[1][2] = cmul(u[1][2], w2);
-                u[1][3] = cmul(u[1][3], w3);
-                u[2][1] = cmul(u[2][1], w2);
-                u[2][2] = cmul_negi(u[2][2]);          // W16^4 = -i
-                u[2][3] = cmul(u[2][3], w6);
-                u[3][1] = cmul(u[3][1], w3);
-                u[3][2] = cmul(u[3][2], w6);
-                u[3][3] = cmul(u[3][3], w9);
-                cplx* zrow = buf + (lane / 10) * MP_ZLD + lane % 10;
+            for (int m = 0; m < 4; ++m) dft4(y[m], y[4 + m], y[8 + m], y[12 + m], u[m]);
+            u[1][1] = cmul(u[1][1], w1);
+            u[1][2] = cmul(u[1][2], w2);
+            u[1][3] = cmul(u[1][3], w3);
+            u[2][1] = cmul(u[2][1], w2);
+            u[2][2] = cmul_negi(u[2][2]);          // W16^4 = -i
+            u[2][3] = cmul(u[2][3], w6);
+            u[3][1] = cmul(u[3][1], w3);
+            u[3][2] = cmul(u[3][2], w6);
+            u[3][3] = cmul(u[3][3], w9);
+            float* prow = power[fb];
+            const bool inner = kb != 0 && kb != MP_K1 - 1;
 #pragma unroll
-                for (int k1 = 0; k1 < 4; ++k1) {
-                    cplx o[4];
-                    dft4(u[0][k1], u[1][k1], u[2][k1], u[3][k1], o);
+            for (int k1 = 0; k1 < 4; ++k1) {
+                cplx o[4];
+                dft4(u[0][k1], u[1][k1], u[2][k1], u[3][k1], o);
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; ++k2) zrow[10 * (k1 + 4 * k2)] = o[k2];
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const int q = k1 + 4 * k2;
+                    const float pw = mp_power(o[k2].re, o[k2].im);
+                    if (q <= 7)
+                        prow[kb + 20 * q] = pw;
+                    else if (q == 8 ? kb != MP_K1 - 1 : inner)
+                        prow[320 - 20 * q - kb] = pw;
                 }
             }
-        }
-        __syncthreads();
-
-        // ---- stage C: real spectrum and power; every lane keeps its twiddle factors in registers -----
-        {
-            // every bin pair is read before the first power is written: one LDS round trip, not six
-            const int kb = 64 + n2, lc = lane & 3;
-            cplx zk[MP_FRAMES], zm[MP_FRAMES];
-#pragma unroll
-            for (int fc = 0; fc < MP_FRAMES; ++fc) {
-                zk[fc] = buf[fc * MP_ZLD + lane];
-                zm[fc] = buf[fc * MP_ZLD + (lane == 0 ? 0 : 160 - lane)];
-            }
-            const cplx zbk = buf[f * MP_ZLD + kb], zbm = buf[f * MP_ZLD + 160 - kb];
-            const cplx zc = buf[lc * MP_ZLD + 80];
-#pragma unroll
-            for (int fc = 0; fc < MP_FRAMES; ++fc) mp_untangle(zk[fc], zm[fc], power[fc], lane, tw_a);
-            mp_untangle(zbk, zbm, power[f], kb, tw_b);
-            if (lane < MP_FRAMES) mp_untangle(zc, zc, power[lane], 80, tw_c);
         }
         __syncthreads();
 
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
             out_utt = __shfl(utt_cur, (lane & 3) * 16);        // lane l < 4 reports frame l of the group
             out_g0 = g0;
         }
-        __syncthreads();                                       // `part` and the transform buffer are reused
+        __syncthreads();                                       // `part` (the transform buffer) is reused
     }
     if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, out_m, out_max, out_utt);
 }
@@ -531,13 +546,11 @@ int lsr_launch_mfcc_ws(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, cons
     if (audio_is_i16)
         hipLaunchKernelGGL(lsr_mel_power_kernel<int16_t>, dim3(blocks_mp), dim3(64), 0, ctx->stream,
                            (const int16_t*)audio_d, frame_info, total_frames, n_groups,
-                           ctx->d_window, ctx->d_tw160, ctx->d_tw320, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots,
-                           mel, uttmax);
+                           ctx->d_window, ctx->d_tw_stage, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots, mel, uttmax);
     else
         hipLaunchKernelGGL(lsr_mel_power_kernel<float>, dim3(blocks_mp), dim3(64), 0, ctx->stream,
                            (const float*)audio_d, frame_info, total_frames, n_groups,
-                           ctx->d_window, ctx->d_tw160, ctx->d_tw320, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots,
-                           mel, uttmax);
+                           ctx->d_window, ctx->d_tw_stage, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots, mel, uttmax);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_mel_power_kernel");
 
