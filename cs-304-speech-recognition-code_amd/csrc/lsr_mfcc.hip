@@ -147,17 +147,32 @@ __device__ __forceinline__ rspec10 rdft10(double a0, cplx a1, cplx a2, double b0
     return r;
 }
 
-// one pass's results: lane = band writes its energy of each frame (a coalesced row per frame), lanes 0..3
-// fold the frame maxima into the utterance maximum (non-negative floats order like their bit patterns)
+// value of the next higher lane (lane 63 gets 0): DPP wave shift left by one
+__device__ __forceinline__ float mp_lane_above(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+// one pass's results: the lane that owns a band writes its energy of each frame (the 40 owners cover a whole row),
+// lanes 0..3 fold the frame maxima into the utterance maximum (non-negative floats order like their bit patterns)
 __device__ __forceinline__ void mp_store_pass(float* __restrict__ mel, unsigned int* __restrict__ uttmax,
-                                              int64_t total_frames, int64_t g0, int lane, const float (&m)[MP_FRAMES],
-                                              float frame_max, int utt) {
-    if (lane < LSR_N_MELS) {
+                                              int64_t total_frames, int64_t g0, int lane, int band,
+                                              const float (&m)[MP_FRAMES], float frame_max, int utt) {
+    if (band >= 0) {
 #pragma unroll
         for (int fd = 0; fd < MP_FRAMES; ++fd)
-            if (g0 + fd < total_frames) mel[(g0 + fd) * LSR_N_MELS + lane] = m[fd];
+            if (g0 + fd < total_frames) mel[(g0 + fd) * LSR_N_MELS + band] = m[fd];
     }
     if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[utt], __float_as_uint(frame_max));
+}
+
+// Ordering point between two stages that exchange data through LDS.  The workgroup is a single wavefront and the
+// LDS executes one wavefront's instructions in issue order, so a stage's reads may queue right behind the previous
+// stage's writes: all that is needed is that the compiler keeps the order.  (A workgroup barrier would first wait
+// for every outstanding write to complete, and the reads would only be issued after that.)
+__device__ __forceinline__ void mp_stage_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <typename SAMPLE>
@@ -168,10 +183,8 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     unsigned int* __restrict__ uttmax) {
     __shared__ __attribute__((aligned(16))) cplx buf[MP_FRAMES * MP_K1 * MP_YLD];   // Y[frame][k1][n2], twiddled
     __shared__ float power[MP_FRAMES][MP_PLD];
-    __shared__ int band_s[2 * LSR_N_MELS];                      // first slot and slot count of each band
     __shared__ __attribute__((aligned(16))) cplx win_s[160];     // window pairs (w[16 (2j) + n2], w[16 (2j + 1) + n2])
     __shared__ __attribute__((aligned(16))) cplx tw_s[10 * 16];  // W320^(n2 k1) as [k1 - 1][n2], k1 = 1..10
-    float(*part)[64] = (float(*)[64])buf;                       // slot sums of the filterbank: the transform buffer is free by then
 
     const int lane = threadIdx.x;
     const int f = lane >> 4, n2 = lane & 15;
@@ -182,7 +195,14 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
         win_s[i] = {window[16 * (2 * j) + m], window[16 * (2 * j + 1) + m]};
         tw_s[i] = {tw_stage[2 * (16 * (j + 1) + m)], tw_stage[2 * (16 * (j + 1) + m) + 1]};
     }
-    for (int i = lane; i < 2 * LSR_N_MELS; i += 64) band_s[i] = band_slots[i];
+    // The slots of a band are consecutive lanes: the lane of a band's first slot adds the band's 1-3 slot sums
+    // (fetched from the lanes above it) and owns the band's energy.
+    int my_band = -1, my_count = 0;
+    for (int b = 0; b < LSR_N_MELS; ++b)
+        if (band_slots[2 * b] == lane) {
+            my_band = b;
+            my_count = band_slots[2 * b + 1];
+        }
     // mel filterbank slot of this lane: up to MP_SLOT_BINS consecutive bins of one band (weights in registers)
     float sw[MP_SLOT_BINS];
 #pragma unroll
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 #pragma unroll
             for (int n1 = 0; n1 < 20; ++n1) asm volatile("" : "+v"(z[n1]));
             asm volatile("" ::: "memory");
-            if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, out_m, out_max, out_utt);
+            if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, my_band, out_m, out_max, out_utt);
             mp_load_samples(audio, info_nxt, n2, xs);
             info_cur = info_nxt;
             info_nxt = mp_load_info(frame_info, total_frames, (grp + 2 * (int64_t)gridDim.x) * MP_FRAMES + f);
@@ -266,16 +286,18 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
                 col[(10 - k) * MP_YLD] = cmul(cplx{ek[k - 1].re - t.re, t.im - ek[k - 1].im}, tv[9 - k]);
             }
         }
-        __syncthreads();
+        mp_stage_fence();
 
         // ---- stage B: 16-point DFTs over n2 for fixed (frame, k1): X[k1 + 20 q], q = 0..15.  Bins up to 160 are
         // wanted: q <= 7 directly (and q = 8 for k1 = 0), the other outputs are the conjugates of the bins
         // 320 - 20 q - k1 (for k1 = 0 and k1 = 10 those repeat bins the lane already has).  The power goes straight
         // to the power table: no second pass over the spectrum -----------------------------------------------
         if (live_b) {
-            cplx y[16];
+            cplx y[16];               // read in the order of use: the first 4-point DFT needs elements 0, 4, 8, 12
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y[i] = buf[lane * MP_YLD + i];
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[4 * j + m] = buf[lane * MP_YLD + 4 * j + m];
             const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178;   // cos, sin(pi/8)
             const double R = 0.70710678118654752440;
             // W16^m = (cos(pi m/8), -sin(pi m/8)) for m = 1,2,3,4,6,9
@@ -309,10 +331,12 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
                 }
             }
         }
-        __syncthreads();
+        mp_stage_fence();
 
-        // ---- stage D: mel filterbank.  Lane = slot (a run of <= 6 bins of one band, weights in
-        // registers, float32 FMA chain); then each band adds its 1-3 slot sums in slot order ----------
+        // ---- stage D: mel filterbank.  Lane = slot (a run of <= 6 bins of one band, weights in registers, float32
+        // FMA chain).  A band's slots are consecutive lanes: its first lane adds the 1-3 slot sums in slot order
+        // (neighbours through DPP wave shifts, no LDS) and keeps the band's energy; the frame maximum is a wave
+        // reduction over those lanes (the energies are non-negative) ------------------------------------------------
         {
             float pv[MP_FRAMES][MP_SLOT_BINS];                 // all reads first, then the FMA chains
 #pragma unroll
@@ -324,26 +348,11 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
                 float acc = sw[0] * pv[fd][0];
 #pragma unroll
                 for (int j = 1; j < MP_SLOT_BINS; ++j) acc = fmaf(sw[j], pv[fd][j], acc);
-                part[fd][lane] = acc;
-            }
-        }
-        __syncthreads();
-        // lane = band (40 lanes): the band's 1-3 slot sums of each frame in slot order, a coalesced row
-        // store per frame, and the frame maximum by a wave reduction (the energies are non-negative)
-        {
-            const int band = lane < LSR_N_MELS ? lane : 0;
-            const int first = band_s[2 * band], count = band_s[2 * band + 1];
-            float pp[MP_FRAMES][3];
-#pragma unroll
-            for (int fd = 0; fd < MP_FRAMES; ++fd)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) pp[fd][j] = part[fd][first + j < 64 ? first + j : 63];
-#pragma unroll
-            for (int fd = 0; fd < MP_FRAMES; ++fd) {
-                float m = pp[fd][0];
-                if (count > 1) m += pp[fd][1];
-                if (count > 2) m += pp[fd][2];
-                const bool live = lane < LSR_N_MELS && g0 + fd < total_frames;
+                const float up1 = mp_lane_above(acc), up2 = mp_lane_above(up1);      // slot sums of lanes + 1, + 2
+                float m = acc;
+                if (my_count > 1) m += up1;
+                if (my_count > 2) m += up2;
+                const bool live = my_band >= 0 && g0 + fd < total_frames;
                 out_m[fd] = m;
                 const float top = lsr_wave_max_f32(live ? m : 0.f);
                 if (lane == fd) out_max = top;                 // lane fd keeps the maximum of frame fd
@@ -351,9 +360,9 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
             out_utt = __shfl(utt_cur, (lane & 3) * 16);        // lane l < 4 reports frame l of the group
             out_g0 = g0;
         }
-        __syncthreads();                                       // `part` (the transform buffer) is reused
+        mp_stage_fence();                                      // the transform buffer and the power table are reused
     }
-    if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, out_m, out_max, out_utt);
+    if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, my_band, out_m, out_max, out_utt);
 }
 
 #define FN_FRAMES 128
