@@ -152,8 +152,9 @@ __device__ __forceinline__ float mp_lane_above(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
 }
 
-// one pass's results: the lane that owns a band writes its energy of each frame (the 40 owners cover a whole row),
-// lanes 0..3 fold the frame maxima into the utterance maximum (non-negative floats order like their bit patterns)
+// one pass's results: the lane that owns a band writes its energy of each frame (the 40 owners cover a whole row);
+// the lanes with utt >= 0 fold their maximum into that utterance's maximum (non-negative floats order like their bit
+// patterns)
 __device__ __forceinline__ void mp_store_pass(float* __restrict__ mel, unsigned int* __restrict__ uttmax,
                                               int64_t total_frames, int64_t g0, int lane, int band,
                                               const float (&m)[MP_FRAMES], float frame_max, int utt) {
@@ -162,7 +163,7 @@ __device__ __forceinline__ void mp_store_pass(float* __restrict__ mel, unsigned 
         for (int fd = 0; fd < MP_FRAMES; ++fd)
             if (g0 + fd < total_frames) mel[(g0 + fd) * LSR_N_MELS + band] = m[fd];
     }
-    if (lane < MP_FRAMES && g0 + lane < total_frames) atomicMax(&uttmax[utt], __float_as_uint(frame_max));
+    if (utt >= 0) atomicMax(&uttmax[utt], __float_as_uint(frame_max));      // lanes that report a frame (or the group)
 }
 
 // Ordering point between two stages that exchange data through LDS.  The workgroup is a single wavefront and the
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
             for (int fd = 0; fd < MP_FRAMES; ++fd)
 #pragma unroll
                 for (int j = 0; j < MP_SLOT_BINS; ++j) pv[fd][j] = power[fd][slot_start + j];
+            const bool owner = my_band >= 0;
 #pragma unroll
             for (int fd = 0; fd < MP_FRAMES; ++fd) {
                 float acc = sw[0] * pv[fd][0];
@@ -352,12 +354,25 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
                 float m = acc;
                 if (my_count > 1) m += up1;
                 if (my_count > 2) m += up2;
-                const bool live = my_band >= 0 && g0 + fd < total_frames;
                 out_m[fd] = m;
-                const float top = lsr_wave_max_f32(live ? m : 0.f);
-                if (lane == fd) out_max = top;                 // lane fd keeps the maximum of frame fd
             }
-            out_utt = __shfl(utt_cur, (lane & 3) * 16);        // lane l < 4 reports frame l of the group
+            // utterance of each frame of the group (held by the first lane of each 16-lane row); in nearly every
+            // group the four frames belong to one utterance and a single reduction and atomic serve all four
+            const int u0 = __builtin_amdgcn_readlane(utt_cur, 0), u1 = __builtin_amdgcn_readlane(utt_cur, 16);
+            const int u2 = __builtin_amdgcn_readlane(utt_cur, 32), u3 = __builtin_amdgcn_readlane(utt_cur, 48);
+            if (u0 == u3 && u1 == u0 && u2 == u0 && g0 + MP_FRAMES <= total_frames) {
+                const float mm = fmaxf(fmaxf(out_m[0], out_m[1]), fmaxf(out_m[2], out_m[3]));
+                out_max = lsr_wave_max_f32(owner ? mm : 0.f);
+                out_utt = lane == 0 ? u0 : -1;                 // lane 0 reports for the group
+            } else {
+#pragma unroll
+                for (int fd = 0; fd < MP_FRAMES; ++fd) {
+                    const float top = lsr_wave_max_f32(owner && g0 + fd < total_frames ? out_m[fd] : 0.f);
+                    if (lane == fd) out_max = top;             // lane fd keeps the maximum of frame fd
+                }
+                const int u = lane == 0 ? u0 : (lane == 1 ? u1 : (lane == 2 ? u2 : u3));
+                out_utt = lane < MP_FRAMES && g0 + lane < total_frames ? u : -1;
+            }
             out_g0 = g0;
         }
         mp_stage_fence();                                      // the transform buffer and the power table are reused
