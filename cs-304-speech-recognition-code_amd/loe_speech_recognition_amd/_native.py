@@ -468,7 +468,10 @@ class Engine:
                                                         fb.total_frames, fb.max_frames, self._ptr(d_off), total_chain,
                                                         self._ptr(d_state), self._ptr(d_band), self._ptr(d_start),
                                                         self._ptr(scores), self._ptr(paths), self._ptr(final)))
-        self.synchronize()     # the chain arrays above must outlive the kernels
+        # The chain arrays must outlive the kernels.  They were allocated on the stream the kernels run on, so the
+        # caching allocator can only hand their memory to work that is ordered after those kernels; holding the
+        # references until the next call keeps that true even if the caller switches torch streams in between.
+        self._chain_keepalive = (d_off, d_state, d_band, d_start)
         return scores, paths, final
 
     def remux_slots(self, paths, fb: "FeatureBatch", chain_off, chain_state, chain_word, n_states: int,
@@ -540,7 +543,7 @@ class Engine:
         d_start, d_off = self.to_device(src_start), self.to_device(dst_off)
         self._check(self.lib.lsr_gather_segments(self.ctx, self._ptr(src), src.element_size(), self._ptr(d_start),
                                                  self._ptr(d_off), lengths.shape[0], int(lengths.max()), self._ptr(dst)))
-        self.synchronize()     # the offset arrays above must outlive the kernel
+        self._gather_keepalive = (d_start, d_off, src)      # as in decode_chain: no host synchronisation needed
         return dst, dst_off
 
 
