@@ -184,18 +184,20 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     unsigned int* __restrict__ uttmax) {
     __shared__ __attribute__((aligned(16))) cplx buf[MP_FRAMES * MP_K1 * MP_YLD];   // Y[frame][k1][n2], twiddled
     __shared__ float power[MP_FRAMES][MP_PLD];
-    __shared__ __attribute__((aligned(16))) cplx win_s[160];     // window pairs (w[16 (2j) + n2], w[16 (2j + 1) + n2])
     __shared__ __attribute__((aligned(16))) cplx tw_s[10 * 16];  // W320^(n2 k1) as [k1 - 1][n2], k1 = 1..10
 
     const int lane = threadIdx.x;
     const int f = lane >> 4, n2 = lane & 15;
-
-    // tables of the first stage live in LDS (read as 16-byte pairs, one bank row per 16 lanes)
     for (int i = lane; i < 160; i += 64) {
         const int j = i >> 4, m = i & 15;
-        win_s[i] = {window[16 * (2 * j) + m], window[16 * (2 * j + 1) + m]};
         tw_s[i] = {tw_stage[2 * (16 * (j + 1) + m)], tw_stage[2 * (16 * (j + 1) + m) + 1]};
     }
+
+    // A lane keeps its column n2 for the whole kernel, so its twenty window values w[16 n1 + n2] and its ten
+    // stage twiddles W320^(n2 k1), k1 = 1..10, are loop constants held in registers
+    double wv[20];
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) wv[n1] = window[16 * n1 + n2];
     // The slots of a band are consecutive lanes: the lane of a band's first slot adds the band's 1-3 slot sums
     // (fetched from the lanes above it) and owns the band's energy.
     int my_band = -1, my_count = 0;
@@ -235,18 +237,12 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
         // ---- stage A: 20-point DFT of the REAL windowed samples 16 n1 + n2 for fixed (frame, n2); the outputs
         // k1 = 0..10 (the rest are their conjugates) times W320^(n2 k1) go to the transform buffer -------------
         {
-            // window pairs and stage twiddles: all twenty LDS reads are in flight before the first use
-            cplx wv[10], tv[10];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) wv[j] = win_s[16 * j + n2];
+            cplx tv[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) tv[k] = tw_s[16 * k + n2];
             double z[20];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                z[2 * j] = wv[j].re * (double)xs[2 * j];
-                z[2 * j + 1] = wv[j].im * (double)xs[2 * j + 1];
-            }
+            for (int n1 = 0; n1 < 20; ++n1) z[n1] = wv[n1] * (double)xs[n1];
             // The next group's samples travel while this group is transformed.  The loads must be issued
             // after the last read of the current samples: the memory counter is in-order, so a read of
             // `xs` placed after them would wait for the new loads as well.  The empty asm statements pin
@@ -562,7 +558,7 @@ int lsr_launch_mfcc_ws(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, cons
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_frame_index_kernel");
 
-    // persistent single-wave workgroups: eight per CU (two per SIMD, 13.5 KiB of LDS each); each walks over
+    // persistent single-wave workgroups: eight per CU (two per SIMD, 16.8 KiB of LDS each); each walks over
     // groups of 4 frames with a grid stride
     const int64_t n_groups = (total_frames + MP_FRAMES - 1) / MP_FRAMES;
     const unsigned blocks_mp = (unsigned)(n_groups < 256 * 8 ? n_groups : 256 * 8);
