@@ -9,7 +9,11 @@ librosa >= 0.10.2).  The reference holds no test vectors for this stage either.
 This file therefore restates librosa 0.10.x's published algorithm with the
 NumPy/SciPy calls librosa itself makes (np.fft.rfft, scipy.fftpack.dct,
 scipy.signal.savgol_filter) and is checked by known-answer tests
-(tests/test_oracle_mfcc.py), not against librosa output.
+(tests/test_oracle_mfcc.py), not against librosa output.  A second restatement
+of the same chain by other authors (transformers.audio_utils, installed here)
+agrees with it up to the log-mel stage to 1e-5 dB
+(tests/test_oracle_mfcc_crosscheck.py); that rules out a misreading of the
+algorithm, it does not pin the padding mode or librosa's own rounding points.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import it.
 """
