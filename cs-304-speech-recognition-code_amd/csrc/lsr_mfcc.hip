@@ -4,7 +4,8 @@
 // Savitzky-Golay deltas of width 9 -> per-frame z-normalisation of the statics).
 //
 // Kernel 1 (frame index): utterance id of every frame of the ragged batch.
-// Kernel 2 (mel power): persistent single-wavefront workgroups, four frames per pass.  The 320-point real
+// Kernel 2 (mel power): persistent wavefronts (four independent ones per workgroup, sharing the window and
+//   twiddle tables in LDS; three per SIMD), four frames per wavefront pass.  The 320-point real
 //   FFT is factored 20 x 16 on the real samples n = 16 n1 + n2: 16 lanes per frame each do a 20-point DFT of
 //   real input in registers (three radix steps 5, 2, 2; only the outputs k1 = 0..10 are needed, the others are
 //   their conjugates), the twiddled results cross LDS once, and 11 lanes per frame each do a 16-point complex
@@ -81,7 +82,8 @@ __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, co
 #define MP_K1 11             // outputs kept of a 20-point real DFT (k1 = 0..10)
 #define MP_YLD 17            // complex elements per (frame, k1) row: 16 + 1 pad
 #define MP_PLD 164
-#define MP_SLOT_BINS 6       // bins per mel slot (61 slots cover the 260 non-zero weights)
+#define MP_SLOT_BINS 6
+#define MP_WAVES 4           // wavefronts per workgroup: independent workers that share the stage tables in LDS       // bins per mel slot (61 slots cover the 260 non-zero weights)
 
 // The load is unconditional (clamped index): a load under a branch is waited for where the branch
 // joins, which would stall the pipeline in the iteration that issues it.
@@ -102,11 +104,11 @@ __device__ __forceinline__ void mp_load_samples(const SAMPLE* __restrict__ audio
 #pragma unroll
         for (int n1 = 0; n1 < 20; ++n1) xs[n1] = (float)sig[16 * n1];
     } else {
+        // sample 16 n1 + n2 lies in [lo, hi) exactly when n1 lies in [first, last): two per-lane bounds instead of
+        // twenty per-lane sample indices
+        const int first = (lo - n2 + 15) >> 4, last = (hi - n2 + 15) >> 4;
 #pragma unroll
-        for (int n1 = 0; n1 < 20; ++n1) {
-            const int i = n2 + 16 * n1;
-            xs[n1] = (i >= lo && i < hi) ? (float)sig[16 * n1] : 0.f;
-        }
+        for (int n1 = 0; n1 < 20; ++n1) xs[n1] = (n1 >= first && n1 < last) ? (float)sig[16 * n1] : 0.f;
     }
 }
 
@@ -166,7 +168,7 @@ __device__ __forceinline__ void mp_store_pass(float* __restrict__ mel, unsigned 
     if (utt >= 0) atomicMax(&uttmax[utt], __float_as_uint(frame_max));      // lanes that report a frame (or the group)
 }
 
-// Ordering point between two stages that exchange data through LDS.  The workgroup is a single wavefront and the
+// Ordering point between two stages that exchange data through LDS.  A wavefront only touches its own tile and the
 // LDS executes one wavefront's instructions in issue order, so a stage's reads may queue right behind the previous
 // stage's writes: all that is needed is that the compiler keeps the order.  (A workgroup barrier would first wait
 // for every outstanding write to complete, and the reads would only be issued after that.)
@@ -177,27 +179,31 @@ __device__ __forceinline__ void mp_stage_fence() {
 }
 
 template <typename SAMPLE>
-__global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
+__global__ __launch_bounds__(64 * MP_WAVES, 3) void lsr_mel_power_kernel(
     const SAMPLE* __restrict__ audio, const int4* __restrict__ frame_info, int64_t total_frames, int64_t n_groups,
     const double* __restrict__ window, const double* __restrict__ tw_stage, const float* __restrict__ slot_w,
     const int* __restrict__ slot_info, const int* __restrict__ band_slots, float* __restrict__ mel,
     unsigned int* __restrict__ uttmax) {
-    __shared__ __attribute__((aligned(16))) cplx buf[MP_FRAMES * MP_K1 * MP_YLD];   // Y[frame][k1][n2], twiddled
-    __shared__ float power[MP_FRAMES][MP_PLD];
+    // Y[frame][k1][n2], twiddled, one tile per wavefront.  The power table of a pass lies over the start of the same
+    // tile: it is written after the second stage has read its whole input into registers and read before the next
+    // pass's first stage writes the tile again, and one wavefront's LDS operations execute in order.
+    __shared__ __attribute__((aligned(16))) cplx buf_all[MP_WAVES][MP_FRAMES * MP_K1 * MP_YLD];
+    __shared__ __attribute__((aligned(16))) cplx win_s[160];     // window pairs (w[16 (2j) + n2], w[16 (2j + 1) + n2])
     __shared__ __attribute__((aligned(16))) cplx tw_s[10 * 16];  // W320^(n2 k1) as [k1 - 1][n2], k1 = 1..10
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int f = lane >> 4, n2 = lane & 15;
-    for (int i = lane; i < 160; i += 64) {
+    cplx* buf = buf_all[wave];
+    float(*power)[MP_PLD] = (float(*)[MP_PLD])buf_all[wave];
+    static_assert(sizeof(float) * MP_FRAMES * MP_PLD <= sizeof(cplx) * MP_FRAMES * MP_K1 * MP_YLD, "power table fits the tile");
+    const int64_t worker = (int64_t)blockIdx.x * MP_WAVES + wave, n_workers = (int64_t)gridDim.x * MP_WAVES;
+
+    // tables of the first stage live in LDS (read as 16-byte pairs, one bank row per 16 lanes)
+    for (int i = threadIdx.x; i < 160; i += 64 * MP_WAVES) {
         const int j = i >> 4, m = i & 15;
+        win_s[i] = {window[16 * (2 * j) + m], window[16 * (2 * j + 1) + m]};
         tw_s[i] = {tw_stage[2 * (16 * (j + 1) + m)], tw_stage[2 * (16 * (j + 1) + m) + 1]};
     }
-
-    // A lane keeps its column n2 for the whole kernel, so its twenty window values w[16 n1 + n2] and its ten
-    // stage twiddles W320^(n2 k1), k1 = 1..10, are loop constants held in registers
-    double wv[20];
-#pragma unroll
-    for (int n1 = 0; n1 < 20; ++n1) wv[n1] = window[16 * n1 + n2];
     // The slots of a band are consecutive lanes: the lane of a band's first slot adds the band's 1-3 slot sums
     // (fetched from the lanes above it) and owns the band's energy.
     int my_band = -1, my_count = 0;
@@ -217,8 +223,8 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     // software pipeline over the grid-stride loop: samples one group ahead, frame records two ahead,
     // so no load is waited for in the iteration that issues it
     float xs[20];
-    int4 info_cur = mp_load_info(frame_info, total_frames, (int64_t)blockIdx.x * MP_FRAMES + f);
-    int4 info_nxt = mp_load_info(frame_info, total_frames, ((int64_t)blockIdx.x + gridDim.x) * MP_FRAMES + f);
+    int4 info_cur = mp_load_info(frame_info, total_frames, worker * MP_FRAMES + f);
+    int4 info_nxt = mp_load_info(frame_info, total_frames, (worker + n_workers) * MP_FRAMES + f);
     mp_load_samples(audio, info_cur, n2, xs);
     __syncthreads();
 
@@ -230,19 +236,23 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
     int out_utt = 0;
     int64_t out_g0 = -1;
 
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    for (int64_t grp = worker; grp < n_groups; grp += n_workers) {
         const int64_t g0 = grp * MP_FRAMES;
         const int utt_cur = info_cur.z;
 
         // ---- stage A: 20-point DFT of the REAL windowed samples 16 n1 + n2 for fixed (frame, n2); the outputs
         // k1 = 0..10 (the rest are their conjugates) times W320^(n2 k1) go to the transform buffer -------------
         {
-            cplx tv[10];
+            // window pairs and stage twiddles: all twenty LDS reads are in flight before the first use
+            cplx wv[10];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) tv[k] = tw_s[16 * k + n2];
+            for (int j = 0; j < 10; ++j) wv[j] = win_s[16 * j + n2];
             double z[20];
 #pragma unroll
-            for (int n1 = 0; n1 < 20; ++n1) z[n1] = wv[n1] * (double)xs[n1];
+            for (int j = 0; j < 10; ++j) {
+                z[2 * j] = wv[j].re * (double)xs[2 * j];
+                z[2 * j + 1] = wv[j].im * (double)xs[2 * j + 1];
+            }
             // The next group's samples travel while this group is transformed.  The loads must be issued
             // after the last read of the current samples: the memory counter is in-order, so a read of
             // `xs` placed after them would wait for the new loads as well.  The empty asm statements pin
@@ -250,10 +260,6 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
 #pragma unroll
             for (int n1 = 0; n1 < 20; ++n1) asm volatile("" : "+v"(z[n1]));
             asm volatile("" ::: "memory");
-            if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, my_band, out_m, out_max, out_utt);
-            mp_load_samples(audio, info_nxt, n2, xs);
-            info_cur = info_nxt;
-            info_nxt = mp_load_info(frame_info, total_frames, (grp + 2 * (int64_t)gridDim.x) * MP_FRAMES + f);
             // samples 4 c + r, r = 0..3: four 5-point DFTs, two 10-point combinations (even / odd samples), one 20-point
             double a0, b0;
             cplx a1, a2, b1, b2;
@@ -263,14 +269,15 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
             rdft5(z[1], z[5], z[9], z[13], z[17], a0, a1, a2);
             rdft5(z[3], z[7], z[11], z[15], z[19], b0, b1, b2);
             const rspec10 O = rdft10(a0, a1, a2, b0, b1, b2);
+            // The stage twiddles W320^(n2 k1) are fetched two at a time, one pair ahead of their use: with three
+            // wavefronts per SIMD the registers that all ten would occupy next to E and O are not there.  The empty
+            // asm statements keep the compiler from hoisting the reads.
+            asm volatile("" ::: "memory");
+            const cplx* tw_lane = tw_s + n2;                       // tw_lane[16 (k1 - 1)]
             cplx* col = buf + (f * MP_K1) * MP_YLD + n2;
+            cplx ta = tw_lane[16 * 0], tb = tw_lane[16 * 8];       // k1 = 1 and 9
             // Y[k] = E[k] + W20^k O[k], Y[10 - k] = conj(E[k] - W20^k O[k]); Y0, Y10 real, Y5 = E5 - i O5
             col[0] = {E.e0 + O.e0, 0.0};
-            {
-                const double y10 = E.e0 - O.e0;
-                col[10 * MP_YLD] = {y10 * tv[9].re, y10 * tv[9].im};
-            }
-            col[5 * MP_YLD] = cmul(cplx{E.e5, -O.e5}, tv[4]);
             const cplx ek[4] = {E.e1, E.e2, E.e3, E.e4}, ok[4] = {O.e1, O.e2, O.e3, O.e4};
             const double wc[4] = {0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917,
                                   0.30901699437494742410};                                      // cos(k pi / 10)
@@ -278,9 +285,19 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
                                   -0.95105651629515357212};                                     // -sin(k pi / 10)
 #pragma unroll
             for (int k = 1; k <= 4; ++k) {
+                // next pair: k1 = k + 1 and 9 - k; after the last step k1 = 5 and 10
+                const cplx na = tw_lane[16 * k], nb = tw_lane[16 * (k < 4 ? 8 - k : 9)];
+                asm volatile("" ::: "memory");
                 const cplx t = cmul(ok[k - 1], cplx{wc[k - 1], ws[k - 1]});
-                col[k * MP_YLD] = cmul(cadd(ek[k - 1], t), tv[k - 1]);
-                col[(10 - k) * MP_YLD] = cmul(cplx{ek[k - 1].re - t.re, t.im - ek[k - 1].im}, tv[9 - k]);
+                col[k * MP_YLD] = cmul(cadd(ek[k - 1], t), ta);
+                col[(10 - k) * MP_YLD] = cmul(cplx{ek[k - 1].re - t.re, t.im - ek[k - 1].im}, tb);
+                ta = na;
+                tb = nb;
+            }
+            col[5 * MP_YLD] = cmul(cplx{E.e5, -O.e5}, ta);
+            {
+                const double y10 = E.e0 - O.e0;
+                col[10 * MP_YLD] = {y10 * tb.re, y10 * tb.im};
             }
         }
         mp_stage_fence();
@@ -290,18 +307,30 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
         // 320 - 20 q - k1 (for k1 = 0 and k1 = 10 those repeat bins the lane already has).  The power goes straight
         // to the power table: no second pass over the spectrum -----------------------------------------------
         if (live_b) {
-            cplx y[16];               // read in the order of use: the first 4-point DFT needs elements 0, 4, 8, 12
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
+            // the sixteen inputs are read in the order of use (the first 4-point DFT needs elements 0, 4, 8, 12), two
+            // groups of four ahead of the arithmetic: reading all sixteen first would cost 64 registers at the point
+            // where the results start to pile up.  The empty asm statements keep the compiler from hoisting the reads.
+            cplx y[16];
+            auto read_group = [&](int m) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[4 * j + m] = buf[lane * MP_YLD + 4 * j + m];
+            };
+            read_group(0);
+            read_group(1);
+            asm volatile("" ::: "memory");
             const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178;   // cos, sin(pi/8)
             const double R = 0.70710678118654752440;
             // W16^m = (cos(pi m/8), -sin(pi m/8)) for m = 1,2,3,4,6,9
             const cplx w1 = {C1, -S1}, w2 = {R, -R}, w3 = {S1, -C1}, w6 = {-R, -R}, w9 = {-C1, S1};
             cplx u[4][4];                // u[n2][k1] = DFT4 over n1 of y[4 n1 + n2]
 #pragma unroll
-            for (int m = 0; m < 4; ++m) dft4(y[m], y[4 + m], y[8 + m], y[12 + m], u[m]);
+            for (int m = 0; m < 4; ++m) {
+                if (m + 2 < 4) {
+                    read_group(m + 2);
+                    asm volatile("" ::: "memory");
+                }
+                dft4(y[m], y[4 + m], y[8 + m], y[12 + m], u[m]);
+            }
             u[1][1] = cmul(u[1][1], w1);
             u[1][2] = cmul(u[1][2], w2);
             u[1][3] = cmul(u[1][3], w3);
@@ -312,6 +341,7 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
             u[3][2] = cmul(u[3][2], w6);
             u[3][3] = cmul(u[3][3], w9);
             float* prow = power[fb];
+            float* mirror = prow + (20 - kb);        // mirror[20 (15 - q)] = prow[320 - 20 q - kb]: constant offsets >= 0
             const bool inner = kb != 0 && kb != MP_K1 - 1;
 #pragma unroll
             for (int k1 = 0; k1 < 4; ++k1) {
@@ -324,11 +354,19 @@ __global__ __launch_bounds__(64, 2) void lsr_mel_power_kernel(
                     if (q <= 7)
                         prow[kb + 20 * q] = pw;
                     else if (q == 8 ? kb != MP_K1 - 1 : inner)
-                        prow[320 - 20 * q - kb] = pw;
+                        mirror[20 * (15 - q)] = pw;
                 }
             }
         }
         mp_stage_fence();
+
+        // The previous pass's results are stored and the next group's samples requested here, after the second
+        // stage: its sixteen complex values per lane are the kernel's register peak, and the twenty sample
+        // registers are not part of it this way.  (Stores first: the memory counter is in order.)
+        if (out_g0 >= 0) mp_store_pass(mel, uttmax, total_frames, out_g0, lane, my_band, out_m, out_max, out_utt);
+        mp_load_samples(audio, info_nxt, n2, xs);
+        info_cur = info_nxt;
+        info_nxt = mp_load_info(frame_info, total_frames, (grp + 2 * n_workers) * MP_FRAMES + f);
 
         // ---- stage D: mel filterbank.  Lane = slot (a run of <= 6 bins of one band, weights in registers, float32
         // FMA chain).  A band's slots are consecutive lanes: its first lane adds the 1-3 slot sums in slot order
@@ -558,17 +596,18 @@ int lsr_launch_mfcc_ws(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, cons
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_frame_index_kernel");
 
-    // persistent single-wave workgroups: eight per CU (two per SIMD, 16.8 KiB of LDS each); each walks over
-    // groups of 4 frames with a grid stride
+    // persistent wavefronts: three workgroups of four per CU (three per SIMD: <= 168 VGPRs, and 11.7 KiB of LDS per
+    // wavefront plus 5 KiB of tables per workgroup); each wavefront walks over groups of 4 frames with a grid stride
     const int64_t n_groups = (total_frames + MP_FRAMES - 1) / MP_FRAMES;
-    const unsigned blocks_mp = (unsigned)(n_groups < 256 * 8 ? n_groups : 256 * 8);
+    const int64_t wgs_needed = (n_groups + MP_WAVES - 1) / MP_WAVES;
+    const unsigned blocks_mp = (unsigned)(wgs_needed < 3 * (int64_t)ctx->n_cus ? wgs_needed : 3 * (int64_t)ctx->n_cus);
     lsr_prof_begin(ctx, LSR_K_MEL_POWER);
     if (audio_is_i16)
-        hipLaunchKernelGGL(lsr_mel_power_kernel<int16_t>, dim3(blocks_mp), dim3(64), 0, ctx->stream,
+        hipLaunchKernelGGL(lsr_mel_power_kernel<int16_t>, dim3(blocks_mp), dim3(64 * MP_WAVES), 0, ctx->stream,
                            (const int16_t*)audio_d, frame_info, total_frames, n_groups,
                            ctx->d_window, ctx->d_tw_stage, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots, mel, uttmax);
     else
-        hipLaunchKernelGGL(lsr_mel_power_kernel<float>, dim3(blocks_mp), dim3(64), 0, ctx->stream,
+        hipLaunchKernelGGL(lsr_mel_power_kernel<float>, dim3(blocks_mp), dim3(64 * MP_WAVES), 0, ctx->stream,
                            (const float*)audio_d, frame_info, total_frames, n_groups,
                            ctx->d_window, ctx->d_tw_stage, ctx->d_slot_w, ctx->d_slot_info, ctx->d_band_slots, mel, uttmax);
     lsr_prof_end(ctx);
