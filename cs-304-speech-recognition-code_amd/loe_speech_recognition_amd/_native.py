@@ -198,6 +198,7 @@ class Engine:
         self._check(self.lib.lsr_set_stream(self.ctx, c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         self._model_token = None
         self._graph_token = None
+        self._rotated = {}               # token -> triangularised whitening matrices (at most 8 kept)
         self._between = None
 
     # -- helpers ----------------------------------------------------------------------------------
@@ -287,7 +288,16 @@ class Engine:
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         whiten = np.ascontiguousarray(whiten, dtype=np.float64)
         if triangular:
-            whiten = np.tril(np.swapaxes(np.linalg.qr(np.swapaxes(whiten, 1, 2), mode="r"), 1, 2))      # batched
+            # callers that alternate between a few models (a loop decoder and an isolated-word collection, say)
+            # switch tokens on every call: the rotation of a token's matrices is kept, only the upload repeats
+            cached = self._rotated.get(token) if token is not None else None
+            if cached is None:
+                cached = np.tril(np.swapaxes(np.linalg.qr(np.swapaxes(whiten, 1, 2), mode="r"), 1, 2))      # batched
+                if token is not None:
+                    if len(self._rotated) >= 8:
+                        self._rotated.pop(next(iter(self._rotated)))
+                    self._rotated[token] = cached
+            whiten = cached
         log_norm = np.ascontiguousarray(log_norm, dtype=np.float64)
         S = mean.shape[0]
         assert mean.shape == (S, DIM) and whiten.shape == (S, DIM, DIM) and log_norm.shape == (S,)

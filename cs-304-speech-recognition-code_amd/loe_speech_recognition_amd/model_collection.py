@@ -65,7 +65,8 @@ class ModelCollection:
         scores = self.scores_batch(signals)
         # model_collection.py:26-28 sorts (label, score) pairs with a stable sort, reverse=True:
         # among equal scores the model that comes first in the collection wins = first argmax
-        return [str(self._models[int(np.argmax(row))]) for row in scores]
+        names = [str(m) for m in self._models]
+        return [names[i] for i in np.argmax(scores, axis=1).tolist()]
 
     def predict(self, signal: np.ndarray) -> str:
         return self.predict_batch([signal])[0]
