@@ -5,7 +5,8 @@
 // ([x, 1]: 40 columns, holding sum_xx, sum_x and the count at once), which is matrix-unit work:
 //   1. a stable counting sort of the frame indices by slot (per-wavefront histograms of 1024-frame
 //      units, a scan over units, a scatter that ranks equal slots inside a wavefront by lane),
-//   2. one wavefront per (slot, part of the slot's sorted list): v_mfma_f64_16x16x4_f64 with four
+//   2. one wavefront per part (up to 512 consecutive frames of a slot's sorted list, so that a slot with many
+//      frames - silence - gets proportionally many wavefronts): v_mfma_f64_16x16x4_f64 with four
 //      frames per k-step; lane (g, c) loads features c, 16 + c, 32 + c of frame 4 ks + g, and the same
 //      register is the A operand (X^T) of its row tile and the B operand (X) of its column tile, so
 //      a k-step is 3 gathers and 6 MFMAs (upper triangle of the 3 x 3 tiles),
@@ -18,6 +19,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define SS_UNIT 1024         // frames per wavefront in the sort kernels
 #define SS_TILES 6           // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
 #define SS_AUG 40            // 39 features + the constant
+#define SS_CHUNK 512         // frames per wavefront of the Gram kernel (a multiple of 16)
 
 __global__ __launch_bounds__(64) void lsr_slot_count_kernel(const int32_t* __restrict__ slot, int64_t total_frames,
                                                             int n_slots, int32_t* __restrict__ counts) {
@@ -70,12 +72,19 @@ __global__ __launch_bounds__(256) void lsr_slot_scan_kernel(int32_t* __restrict_
     if (threadIdx.x == 0) slot_n[blockIdx.x] = total;
 }
 
-// slot_base[slot] = start of the slot's segment
+// slot_base[slot] = start of the slot's segment; part_base[slot] = first part (chunk of SS_CHUNK frames) of the
+// slot in the list of all parts, part_base[n_slots] = number of parts
 __global__ __launch_bounds__(256) void lsr_slot_base_kernel(const int32_t* __restrict__ slot_n, int n_slots,
-                                                            int32_t* __restrict__ slot_base) {
-    for (int i = threadIdx.x; i < n_slots; i += 256) slot_base[i] = slot_n[i];
+                                                            int32_t* __restrict__ slot_base,
+                                                            int32_t* __restrict__ part_base) {
+    for (int i = threadIdx.x; i < n_slots; i += 256) {
+        slot_base[i] = slot_n[i];
+        part_base[i] = (slot_n[i] + SS_CHUNK - 1) / SS_CHUNK;
+    }
     __syncthreads();
     ss_block_scan(slot_base, n_slots);
+    const int total = ss_block_scan(part_base, n_slots);
+    if (threadIdx.x == 0) part_base[n_slots] = total;
 }
 
 __global__ __launch_bounds__(64) void lsr_slot_scatter_kernel(const int32_t* __restrict__ slot, int64_t total_frames,
@@ -124,24 +133,32 @@ __device__ __forceinline__ void ss_load(const float* __restrict__ feats, const i
 
 __global__ __launch_bounds__(64) void lsr_gram_kernel(const float* __restrict__ feats, const int32_t* __restrict__ order,
                                                       const int32_t* __restrict__ slot_base,
-                                                      const int32_t* __restrict__ slot_n, int n_parts,
+                                                      const int32_t* __restrict__ slot_n,
+                                                      const int32_t* __restrict__ part_base, int n_slots,
                                                       v4d* __restrict__ partial) {
-    const int s = blockIdx.x / n_parts, part = blockIdx.x % n_parts;
+    const int b = blockIdx.x;
+    if (b >= part_base[n_slots]) return;                 // the grid is sized for the worst case
+    // slot of this part: the last slot whose first part is <= b (slots without frames have no parts)
+    int lo = 0, hi = n_slots;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (part_base[mid] <= b) lo = mid; else hi = mid;
+    }
+    const int s = lo, part = b - part_base[s];
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    const int n = slot_n[s], base = slot_base[s];
-    const int n_ks = (n + 3) / 4;
-    const int ks0 = (int)((int64_t)part * n_ks / n_parts), ks1 = (int)((int64_t)(part + 1) * n_ks / n_parts);
-    const int end = base + n;
+    const int first = slot_base[s] + part * SS_CHUNK;
+    const int seg_end = slot_base[s] + slot_n[s];
+    const int end = first + SS_CHUNK < seg_end ? first + SS_CHUNK : seg_end;
     v4d acc[SS_TILES];
 #pragma unroll
     for (int t = 0; t < SS_TILES; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    for (int ks = ks0; ks < ks1; ks += 4) {
-        double x[4][3];
+    // sixteen frames per iteration (four k-steps of four frames), the next sixteen in flight meanwhile
+    double x[4][3], nx[4][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = ks + u;
-            ss_load(feats, order, k < ks1 ? base + 4 * k + g : end, end, c, x[u]);
-        }
+    for (int u = 0; u < 4; ++u) ss_load(feats, order, first + 4 * u + g, end, c, x[u]);
+    for (int pos = first; pos < end; pos += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ss_load(feats, order, pos + 16 + 4 * u + g, end, c, nx[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][0], x[u][0], acc[0], 0, 0, 0);
@@ -151,58 +168,75 @@ __global__ __launch_bounds__(64) void lsr_gram_kernel(const float* __restrict__ 
             acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][1], x[u][2], acc[4], 0, 0, 0);
             acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][2], x[u][2], acc[5], 0, 0, 0);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[u][k] = nx[u][k];
     }
-    v4d* out = partial + ((size_t)blockIdx.x * SS_TILES) * 64 + lane;
+    v4d* out = partial + ((size_t)b * SS_TILES) * 64 + lane;
 #pragma unroll
     for (int t = 0; t < SS_TILES; ++t) out[t * 64] = acc[t];
 }
 
 // entry (i, j), i <= j, of the augmented Gram matrix lives in tile (i / 16, j / 16) at lane
 // (i % 4) * 16 + j % 16, register (i % 16) / 4
-__global__ __launch_bounds__(256) void lsr_gram_reduce_kernel(const double* __restrict__ partial, int n_parts,
+// One thread per entry of a slot's augmented Gram matrix (blockIdx.y selects the 256 entries): the slot's parts are
+// added in list order - a fixed order of additions - with eight loads in flight.
+__global__ __launch_bounds__(256) void lsr_gram_reduce_kernel(const double* __restrict__ partial,
+                                                              const int32_t* __restrict__ part_base,
                                                               double* __restrict__ count, double* __restrict__ sum_x,
                                                               double* __restrict__ sum_xx) {
     const int s = blockIdx.x;
-    for (int e = threadIdx.x; e < SS_AUG * SS_AUG; e += 256) {
-        int i = e / SS_AUG, j = e % SS_AUG;
-        const int row = i, colm = j;
-        if (i > j) {
-            const int t = i;
-            i = j;
-            j = t;
-        }
-        const int ti = i / 16, tj = j / 16;
-        const int tile = ti == 0 ? tj : (ti == 1 ? 2 + tj : 5);
-        const int lane = (i % 4) * 16 + j % 16, reg = (i % 16) / 4;
-        double t = 0.0;
-        for (int p = 0; p < n_parts; ++p)
-            t += partial[((((size_t)s * n_parts + p) * SS_TILES + tile) * 64 + lane) * 4 + reg];
-        if (row < LSR_DIM && colm < LSR_DIM)
-            sum_xx[((size_t)s * LSR_DIM + row) * LSR_DIM + colm] = t;
-        else if (row == LSR_DIM && colm < LSR_DIM)
-            sum_x[(size_t)s * LSR_DIM + colm] = t;
-        else if (row == LSR_DIM && colm == LSR_DIM)
-            count[s] = t;
+    const int p0 = part_base[s], p1 = part_base[s + 1];
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= SS_AUG * SS_AUG) return;
+    int i = e / SS_AUG, j = e % SS_AUG;
+    const int row = i, colm = j;
+    if (i > j) {
+        const int t = i;
+        i = j;
+        j = t;
     }
+    const int ti = i / 16, tj = j / 16;
+    const int tile = ti == 0 ? tj : (ti == 1 ? 2 + tj : 5);
+    const int lane = (i % 4) * 16 + j % 16, reg = (i % 16) / 4;
+    const double* src = partial + ((size_t)tile * 64 + lane) * 4 + reg;
+    const size_t stride = (size_t)SS_TILES * 64 * 4;              // doubles per part
+    double t = 0.0;
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(p + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; p < p1; ++p) t += src[(size_t)p * stride];
+    if (row < LSR_DIM && colm < LSR_DIM)
+        sum_xx[((size_t)s * LSR_DIM + row) * LSR_DIM + colm] = t;
+    else if (row == LSR_DIM && colm < LSR_DIM)
+        sum_x[(size_t)s * LSR_DIM + colm] = t;
+    else if (row == LSR_DIM && colm == LSR_DIM)
+        count[s] = t;
 }
 
 int lsr_launch_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, int64_t total_frames, int n_slots,
                      double* count_d, double* sum_x_d, double* sum_xx_d) {
     const int n_units = (int)((total_frames + SS_UNIT - 1) / SS_UNIT);
-    int n_parts = 4096 / n_slots;
-    if (n_parts < 1) n_parts = 1;
-    if (n_parts > 256) n_parts = 256;
-    // sort workspace: counts/offsets [slots][units], slot_base, slot_n, order [frames]
+    // every slot with frames has at most one part that is not full
+    const size_t max_parts = (size_t)(total_frames / SS_CHUNK) + (size_t)n_slots;
+    // sort workspace: counts/offsets [slots][units], slot_base, slot_n, part_base [slots + 1], order [frames]
     const size_t n_counts = (size_t)n_units * n_slots;
-    const size_t sort_ints = n_counts + 2 * (size_t)n_slots + (size_t)total_frames;
+    const size_t sort_ints = n_counts + 3 * (size_t)n_slots + 1 + (size_t)total_frames;
     int rc = lsr_reserve(ctx, &ctx->ws_sort, sort_ints * sizeof(int32_t), "slot sort");
     if (rc) return rc;
-    const size_t partial_bytes = (size_t)n_slots * n_parts * SS_TILES * 64 * sizeof(v4d);
+    const size_t partial_bytes = max_parts * SS_TILES * 64 * sizeof(v4d);
     if ((rc = lsr_reserve(ctx, &ctx->ws_slab, partial_bytes, "statistics partial sums"))) return rc;
     int32_t* counts = (int32_t*)ctx->ws_sort.ptr;
     int32_t* slot_base = counts + n_counts;
     int32_t* slot_n = slot_base + n_slots;
-    int32_t* order = slot_n + n_slots;
+    int32_t* part_base = slot_n + n_slots;
+    int32_t* order = part_base + n_slots + 1;
     v4d* partial = (v4d*)ctx->ws_slab.ptr;
     const size_t lds = (size_t)n_slots * sizeof(int);
     lsr_prof_begin(ctx, LSR_K_STATS);
@@ -211,16 +245,16 @@ int lsr_launch_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, 
     LSR_LAUNCH_CHECK(ctx, "lsr_slot_count_kernel");
     hipLaunchKernelGGL(lsr_slot_scan_kernel, dim3(n_slots), dim3(256), 0, ctx->stream, counts, n_units, slot_n);
     LSR_LAUNCH_CHECK(ctx, "lsr_slot_scan_kernel");
-    hipLaunchKernelGGL(lsr_slot_base_kernel, dim3(1), dim3(256), 0, ctx->stream, slot_n, n_slots, slot_base);
+    hipLaunchKernelGGL(lsr_slot_base_kernel, dim3(1), dim3(256), 0, ctx->stream, slot_n, n_slots, slot_base, part_base);
     LSR_LAUNCH_CHECK(ctx, "lsr_slot_base_kernel");
     hipLaunchKernelGGL(lsr_slot_scatter_kernel, dim3(n_units), dim3(64), lds, ctx->stream, slot_d, total_frames, n_slots,
                        counts, slot_base, order);
     LSR_LAUNCH_CHECK(ctx, "lsr_slot_scatter_kernel");
-    hipLaunchKernelGGL(lsr_gram_kernel, dim3((unsigned)(n_slots * n_parts)), dim3(64), 0, ctx->stream, feats_d, order,
-                       slot_base, slot_n, n_parts, partial);
+    hipLaunchKernelGGL(lsr_gram_kernel, dim3((unsigned)max_parts), dim3(64), 0, ctx->stream, feats_d, order, slot_base,
+                       slot_n, part_base, n_slots, partial);
     LSR_LAUNCH_CHECK(ctx, "lsr_gram_kernel");
-    hipLaunchKernelGGL(lsr_gram_reduce_kernel, dim3((unsigned)n_slots), dim3(256), 0, ctx->stream,
-                       (const double*)partial, n_parts, count_d, sum_x_d, sum_xx_d);
+    hipLaunchKernelGGL(lsr_gram_reduce_kernel, dim3((unsigned)n_slots, (SS_AUG * SS_AUG + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const double*)partial, part_base, count_d, sum_x_d, sum_xx_d);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_gram_reduce_kernel");
     return LSR_OK;
@@ -239,36 +273,64 @@ int lsr_launch_utt_index(lsr_ctx* ctx, const int64_t* off_d, int n_utts, int32_t
     return LSR_OK;
 }
 
+#define RM_FRAMES 4096       // frames per workgroup of the re-mux kernel
+#define RM_LDS_STATES 128    // largest model whose transition table (n x n counters) is kept in LDS
+
+// Transition counts concentrate on a few hundred (state, state) pairs, so one global atomic per frame would
+// serialise on those addresses: a workgroup counts its 4 096 frames in an LDS table and adds the non-zero
+// entries to the global table once (integer sums: the order does not matter).  Models too large for the LDS
+// table count in global memory directly.
 __global__ __launch_bounds__(256) void lsr_remux_kernel(const int8_t* __restrict__ paths,
                                                         const int64_t* __restrict__ frame_off,
                                                         const int64_t* __restrict__ chain_off,
                                                         const int32_t* __restrict__ chain_state,
                                                         const int32_t* __restrict__ chain_word,
                                                         const int32_t* __restrict__ frame_utt, int64_t total_frames,
-                                                        int n_states, int drop_last_run, int32_t* __restrict__ slots,
+                                                        int n_states, int drop_last_run, int use_lds,
+                                                        int32_t* __restrict__ slots,
                                                         unsigned long long* __restrict__ trans) {
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= total_frames) return;
-    const int b = frame_utt[f];
-    const int64_t c0 = chain_off[b], n_chain = chain_off[b + 1] - c0;
-    const int64_t last = frame_off[b + 1] - 1;
-    const int p = paths[f];
-    if (p < 0 || p >= n_chain) {        // only a one-frame utterance has no back-pointer (-1)
-        slots[f] = -1;
-        return;
+    extern __shared__ unsigned int local_trans[];
+    const int n_entries = n_states * n_states;
+    if (use_lds) {
+        for (int e = threadIdx.x; e < n_entries; e += 256) local_trans[e] = 0u;
+        __syncthreads();
     }
-    const int pl = paths[last];
-    const int w_last = (pl >= 0 && pl < n_chain) ? chain_word[c0 + pl] : -1;
-    const int g = chain_state[c0 + p], w = chain_word[c0 + p];
-    const bool keep = !drop_last_run || w != w_last;
-    slots[f] = (keep && g >= 0 && g < n_states) ? g : -1;
-    if (keep && f < last) {
-        const int p1 = paths[f + 1];
-        if (p1 >= 0 && p1 < n_chain) {
-            const int g1 = chain_state[c0 + p1], w1 = chain_word[c0 + p1];
-            const bool keep1 = !drop_last_run || w1 != w_last;
-            if (keep1 && w1 == w && g >= 0 && g < n_states && g1 >= 0 && g1 < n_states)
-                atomicAdd(&trans[(size_t)g * n_states + g1], 1ull);
+    const int64_t f0 = (int64_t)blockIdx.x * RM_FRAMES;
+    for (int it = 0; it < RM_FRAMES / 256; ++it) {
+        const int64_t f = f0 + it * 256 + threadIdx.x;
+        if (f >= total_frames) break;
+        const int b = frame_utt[f];
+        const int64_t c0 = chain_off[b], n_chain = chain_off[b + 1] - c0;
+        const int64_t last = frame_off[b + 1] - 1;
+        const int p = paths[f];
+        if (p < 0 || p >= n_chain) {        // only a one-frame utterance has no back-pointer (-1)
+            slots[f] = -1;
+            continue;
+        }
+        const int pl = paths[last];
+        const int w_last = (pl >= 0 && pl < n_chain) ? chain_word[c0 + pl] : -1;
+        const int g = chain_state[c0 + p], w = chain_word[c0 + p];
+        const bool keep = !drop_last_run || w != w_last;
+        slots[f] = (keep && g >= 0 && g < n_states) ? g : -1;
+        if (keep && f < last) {
+            const int p1 = paths[f + 1];
+            if (p1 >= 0 && p1 < n_chain) {
+                const int g1 = chain_state[c0 + p1], w1 = chain_word[c0 + p1];
+                const bool keep1 = !drop_last_run || w1 != w_last;
+                if (keep1 && w1 == w && g >= 0 && g < n_states && g1 >= 0 && g1 < n_states) {
+                    if (use_lds)
+                        atomicAdd(&local_trans[g * n_states + g1], 1u);
+                    else
+                        atomicAdd(&trans[(size_t)g * n_states + g1], 1ull);
+                }
+            }
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_entries; e += 256) {
+            const unsigned int c = local_trans[e];
+            if (c) atomicAdd(&trans[e], (unsigned long long)c);
         }
     }
 }
@@ -289,9 +351,11 @@ extern "C" int lsr_remux_slots(lsr_ctx* ctx, const int8_t* paths_d, const int64_
     LSR_HIP_CHECK(ctx, hipMemsetAsync(trans_d, 0, (size_t)n_states * n_states * sizeof(int64_t), ctx->stream));
     hipLaunchKernelGGL(lsr_utt_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, frame_off_d, frame_utt);
     LSR_LAUNCH_CHECK(ctx, "lsr_utt_index_kernel");
-    hipLaunchKernelGGL(lsr_remux_kernel, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, ctx->stream, paths_d,
-                       frame_off_d, chain_off_d, chain_state_d, chain_word_d, frame_utt, total_frames, n_states,
-                       drop_last_run, slots_d, (unsigned long long*)trans_d);
+    const int use_lds = n_states <= RM_LDS_STATES;
+    const size_t lds = use_lds ? (size_t)n_states * n_states * sizeof(unsigned int) : 0;
+    hipLaunchKernelGGL(lsr_remux_kernel, dim3((unsigned)((total_frames + RM_FRAMES - 1) / RM_FRAMES)), dim3(256), lds,
+                       ctx->stream, paths_d, frame_off_d, chain_off_d, chain_state_d, chain_word_d, frame_utt, total_frames,
+                       n_states, drop_last_run, use_lds, slots_d, (unsigned long long*)trans_d);
     LSR_LAUNCH_CHECK(ctx, "lsr_remux_kernel");
     return LSR_OK;
 }

@@ -484,6 +484,27 @@ class Engine:
         self._chain_keepalive = (d_off, d_state, d_band, d_start)
         return scores, paths, final
 
+    def decode_chain_device(self, fb: FeatureBatch, d_off, total_chain: int, d_state, d_band, d_start, wide: bool = False,
+                            want_paths: bool = True):
+        """decode_chain for a chain description that already lives on the device (int64 offsets [B + 1], int32
+        model state, float32 band [3, total_chain], uint8 start flags per chain position), as a trainer keeps it
+        between iterations: no host validation, no upload.  Returns (scores, paths)."""
+        t = self.torch
+        assert d_off.dtype == t.int64 and d_state.dtype == t.int32 and d_band.dtype == t.float32 and d_start.dtype == t.uint8
+        assert d_off.shape == (fb.n + 1,) and d_state.shape == (total_chain,) and d_band.shape == (3, total_chain)
+        assert d_start.shape == (total_chain,) and d_band.is_contiguous()
+        scores = self.empty((fb.n,), t.float32)
+        paths = self.empty((fb.total_frames,), t.int8) if want_paths else None
+        fn = self.lib.lsr_decode_chain_batch_wide if wide else self.lib.lsr_decode_chain_batch
+        args = [self.ctx, self._ptr(fb.feats), self._ptr(fb.frame_off), fb.n, fb.total_frames, fb.max_frames, self._ptr(d_off),
+                total_chain, self._ptr(d_state), self._ptr(d_band), self._ptr(d_start), self._ptr(scores), self._ptr(paths)]
+        if not wide:
+            args.append(c_void_p(0))
+        self._check(fn(*args))
+        self.last_chain = (d_off, d_state)
+        self._chain_keepalive = (d_off, d_state, d_band, d_start)
+        return scores, paths
+
     def remux_slots(self, paths, fb: "FeatureBatch", chain_off, chain_state, chain_word, n_states: int,
                     drop_last_run: bool):
         """(slots int32[total_frames], transition counts int64[n_states, n_states]) device tensors.

@@ -676,7 +676,9 @@ class HiddenMarkovModelTrainContinuous:
         labels = self._models_loaded
         model_band = np.concatenate([self._trainable_models[lab]._log_transition_probs.band() for lab in labels], axis=1)
         cache = self.__dict__.get("_chain_cache")
-        if cache is not None and cache["owner"] is owner:      # the structure only depends on the label strings
+        layout = tuple((lab, self._trainable_models[lab].num_of_states) for lab in labels)
+        # the structure only depends on the label strings and on the order and sizes of the models
+        if cache is not None and cache["owner"] is owner and cache["layout"] == layout:
             off, ids, start, ordinal, cross1, cross2 = cache["arrays"]
             band = model_band[:, ids]
             band[1, cross1] = 0.0
@@ -713,18 +715,41 @@ class HiddenMarkovModelTrainContinuous:
         start[off[:-1]] = 1
         ids = ids.astype(np.int32)
         ordinal = ordinal.astype(np.int64)
-        self.__dict__["_chain_cache"] = {"owner": owner, "arrays": (off, ids, start, ordinal, cross1, cross2)}
+        self.__dict__["_chain_cache"] = {"owner": owner, "layout": layout, "arrays": (off, ids, start, ordinal, cross1, cross2)}
         return off, ids, band.astype(np.float32), start, ordinal, n_total
 
     def _align(self, fb, owner: List[str]):
         """Forced alignment of every utterance against S d S d ... S (hidden_markov_model.py:772-782)
-        in one device call.  Returns the device paths (chain positions) and the chain description."""
+        in one device call.  Returns the device paths (chain positions) and the chain description.
+        The structure of the chains (offsets, model states, start flags, which band entries cross a word
+        boundary) only depends on the label strings and stays on the device between iterations; what changes
+        is the 3 x n_states band of the models, which is uploaded and spread over the chain positions there."""
         eng = _native.get_engine()
+        t = eng.torch
         models = [self._trainable_models[lab] for lab in self._models_loaded]
         eng.set_model(_native.new_token(), *stack_gaussians([g for m in models for g in m._multivariate_normals]))
-        off, ids, band, start, ordinal, n_total = self._chains(owner)
-        _, paths, _ = eng.decode_chain(fb, off, ids, band, start)
-        return paths, off, ids, ordinal, n_total
+        cache = self.__dict__.get("_chain_cache")
+        layout = tuple((lab, self._trainable_models[lab].num_of_states) for lab in self._models_loaded)
+        if cache is None or cache["owner"] is not owner or cache["layout"] != layout or "d_ids" not in cache:
+            off, ids, _, start, ordinal, n_total = self._chains(owner)
+            cache = self.__dict__["_chain_cache"]
+            _, _, _, _, cross1, cross2 = cache["arrays"]
+            if int(np.diff(off).max()) > _native.MAX_STATES:
+                raise ValueError(f"every chain needs 1..{_native.MAX_STATES} states")
+            cache.update(d_off=eng.to_device(off), d_ids=eng.to_device(ids), d_ids_long=eng.to_device(ids.astype(np.int64)),
+                         d_start=eng.to_device(start), d_cross1=eng.to_device(cross1.astype(np.int64)),
+                         d_cross2=eng.to_device(cross2.astype(np.int64)), d_ordinal=eng.to_device(ordinal.astype(np.int32)),
+                         wide=int(np.diff(off).max()) > _native.NARROW_STATES, n_total=n_total)
+        off, ids, _, ordinal = cache["arrays"][0], cache["arrays"][1], None, cache["arrays"][3]
+        model_band = np.concatenate([m._log_transition_probs.band() for m in models], axis=1).astype(np.float32)
+        if np.isnan(model_band).any():
+            raise ValueError("NaN transition log-probability")
+        d_band = eng.to_device(model_band)[:, cache["d_ids_long"]].contiguous()
+        d_band[1, cache["d_cross1"]] = 0.0
+        d_band[2, cache["d_cross2"]] = 0.0
+        _, paths = eng.decode_chain_device(fb, cache["d_off"], int(off[-1]), cache["d_ids"], d_band, cache["d_start"],
+                                           wide=cache["wide"])
+        return paths, off, ids, ordinal, cache["n_total"]
 
     def _iteration(self, labeled_mfccs: Dict[str, List[np.ndarray]]) -> None:
         """Alignment + re-mux + statistics + per-word M-step (hidden_markov_model.py:733-770) without
