@@ -69,3 +69,67 @@ def test_bitwise_reproducible():
     b = device_stats(x, slots, 58)
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
+
+
+def numpy_remux(paths, frame_off, chain_off, chain_state, chain_word, n_states, drop_last_run):
+    paths = paths.astype(np.int64)
+    slots = np.full(paths.shape[0], -1, np.int32)
+    trans = np.zeros((n_states, n_states), np.int64)
+    for b in range(frame_off.shape[0] - 1):
+        lo, hi = int(frame_off[b]), int(frame_off[b + 1])
+        c0 = int(chain_off[b])
+        w_last = chain_word[c0 + paths[hi - 1]]
+        for f in range(lo, hi):
+            g, w = chain_state[c0 + paths[f]], chain_word[c0 + paths[f]]
+            keep = not drop_last_run or w != w_last
+            if keep:
+                slots[f] = g
+            if keep and f + 1 < hi:
+                g1, w1 = chain_state[c0 + paths[f + 1]], chain_word[c0 + paths[f + 1]]
+                if (not drop_last_run or w1 != w_last) and w1 == w:
+                    trans[g, g1] += 1
+    return slots, trans
+
+
+@pytest.mark.parametrize("n_states,drop", [(5, False), (58, True), (128, True), (131, True)])
+def test_remux_slots_and_transition_counts(n_states, drop):
+    """Path -> statistics slot and transition counts (lsr_remux_slots) against a per-frame Python loop; 128 states is
+    the largest transition table counted in LDS, 131 takes the global-atomic path."""
+    eng = _native.get_engine()
+    rng = np.random.default_rng(n_states)
+    word_size = 5 if n_states >= 5 else n_states
+    n_words_model = n_states // word_size
+    B = 300
+    lens = rng.integers(1, 120, size=B)
+    frame_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    chain_off, chain_state, chain_word, paths = [0], [], [], []
+    for b in range(B):
+        n_w = int(rng.integers(1, 9))
+        for k in range(n_w):
+            w = int(rng.integers(n_words_model))
+            chain_state.extend(range(w * word_size, (w + 1) * word_size))
+            chain_word.extend([k] * word_size)
+        n_chain = n_w * word_size
+        chain_off.append(chain_off[-1] + n_chain)
+        steps = rng.integers(0, 3, size=lens[b])                  # a left-to-right walk with skips
+        steps[0] = 0
+        paths.append(np.minimum(np.cumsum(steps), n_chain - 1))
+    paths = np.concatenate(paths).astype(np.int8)
+    chain_off = np.asarray(chain_off, np.int64)
+    chain_state = np.asarray(chain_state, np.int32)
+    chain_word = np.asarray(chain_word, np.int32)
+    want_slots, want_trans = numpy_remux(paths, frame_off, chain_off, chain_state, chain_word, n_states, drop)
+    t = eng.torch
+    slots = eng.empty((paths.shape[0],), t.int32)
+    trans = eng.empty((n_states, n_states), t.int64)
+    # the device copies are held in variables for the duration of the calls
+    d_paths, d_frame_off, d_chain_off = eng.to_device(paths), eng.to_device(frame_off), eng.to_device(chain_off)
+    d_state, d_word = eng.to_device(chain_state), eng.to_device(chain_word)
+    for _ in range(2):                                            # twice: the table is cleared per call
+        eng._check(eng.lib.lsr_remux_slots(eng.ctx, eng._ptr(d_paths), eng._ptr(d_frame_off), eng._ptr(d_chain_off),
+                                           eng._ptr(d_state), eng._ptr(d_word), B, paths.shape[0], n_states,
+                                           1 if drop else 0, eng._ptr(slots), eng._ptr(trans)))
+        eng.synchronize()
+    assert np.array_equal(slots.cpu().numpy(), want_slots)
+    assert np.array_equal(trans.cpu().numpy(), want_trans)
+    assert want_trans.sum() > 1000
