@@ -151,6 +151,6 @@ int lsr_launch_viterbi_chain(lsr_ctx* ctx, const float* ll_d, const int64_t* fra
                              int64_t total_chain, const int32_t* chain_state_d,
                              const float* chain_band_d, const uint8_t* chain_start_d,
                              float* scores_d, int8_t* paths_d, float* final_d, bool wide = false);
-int lsr_launch_utt_index(lsr_ctx* ctx, const int64_t* off_d, int n_utts, int32_t* out_d);
+int lsr_launch_utt_index(lsr_ctx* ctx, const int64_t* off_d, int n_utts, int64_t total, int32_t* out_d);
 int lsr_launch_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, int64_t total_frames,
                      int n_slots, double* count_d, double* sum_x_d, double* sum_xx_d);

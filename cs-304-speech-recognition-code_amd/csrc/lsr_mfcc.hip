@@ -62,9 +62,25 @@ __device__ __forceinline__ void dft4(const cplx a, const cplx b, const cplx c, c
 // window (may lie before the clip), z = utterance, w = [lo, hi) range of window samples that fall
 // inside the clip (lo | hi << 16); the rest of the window is the zero padding.
 __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, const int64_t* __restrict__ sample_off,
-                                       int32_t* __restrict__ frame_utt, int4* __restrict__ frame_info) {
+                                       int64_t total_frames, int32_t* __restrict__ frame_utt,
+                                       int4* __restrict__ frame_info) {
     const int b = blockIdx.x;
-    const int64_t lo = frame_off[b], hi = frame_off[b + 1];
+    const int64_t lo = frame_off[b];
+    int64_t hi = frame_off[b + 1];
+    if (hi > total_frames) hi = total_frames;           // the tables hold total_frames entries whatever the offsets say
+    if (lo < 0) return;
+    // frames before the first and after the last utterance's range (offsets that do not span the batch) get an empty
+    // record of utterance 0: nothing downstream reads through a stale entry
+    if (b == 0)
+        for (int64_t f = threadIdx.x; f < lo && f < total_frames; f += blockDim.x) {
+            frame_utt[f] = 0;
+            frame_info[f] = make_int4(0, 0, 0, 0);
+        }
+    if (b == (int)gridDim.x - 1)
+        for (int64_t f = (hi < 0 ? 0 : hi) + threadIdx.x; f < total_frames; f += blockDim.x) {
+            frame_utt[f] = 0;
+            frame_info[f] = make_int4(0, 0, 0, 0);
+        }
     const int64_t s0 = sample_off[b], ns = sample_off[b + 1] - s0;
     for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) {
         frame_utt[f] = b;
@@ -592,7 +608,7 @@ int lsr_launch_mfcc_ws(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, cons
 
     lsr_prof_begin(ctx, LSR_K_FRAME_INDEX);
     hipLaunchKernelGGL(lsr_frame_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, frame_off_d, sample_off_d,
-                       frame_utt, frame_info);
+                       total_frames, frame_utt, frame_info);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_frame_index_kernel");
 

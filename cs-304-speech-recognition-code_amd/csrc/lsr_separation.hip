@@ -164,7 +164,7 @@ extern "C" int lsr_separation_scan(lsr_ctx* ctx, const void* audio_d, int audio_
     int32_t* frame_utt = (int32_t*)ctx->ws_frame_utt.ptr;
     float* fmax = (float*)ctx->ws_sep.ptr;
     float* energy = energy_d ? energy_d : fmax + total_scan_frames;
-    rc = lsr_launch_utt_index(ctx, scan_off_d, n_utts, frame_utt);
+    rc = lsr_launch_utt_index(ctx, scan_off_d, n_utts, total_scan_frames, frame_utt);
     if (rc) return rc;
     LSR_HIP_CHECK(ctx, hipMemsetAsync(noise_d, 0, (size_t)total_scan_frames, ctx->stream));
     const dim3 grid((unsigned)((total_scan_frames + 15) / 16));

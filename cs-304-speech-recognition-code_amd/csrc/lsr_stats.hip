@@ -261,14 +261,18 @@ int lsr_launch_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, 
 }
 
 // ---- path -> statistics slots and transition counts (integer work, one thread per frame) -------------
-__global__ void lsr_utt_index_kernel(const int64_t* __restrict__ frame_off, int32_t* __restrict__ frame_utt) {
+// The offsets come from the caller's device buffer: ranges are clamped to the table, so that inconsistent offsets
+// give wrong results in the caller's own outputs rather than writes outside the workspace.
+__global__ void lsr_utt_index_kernel(const int64_t* __restrict__ frame_off, int64_t total, int32_t* __restrict__ frame_utt) {
     const int b = blockIdx.x;
-    const int64_t lo = frame_off[b], hi = frame_off[b + 1];
+    int64_t lo = frame_off[b], hi = frame_off[b + 1];
+    if (lo < 0) lo = 0;
+    if (hi > total) hi = total;
     for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) frame_utt[f] = b;
 }
 
-int lsr_launch_utt_index(lsr_ctx* ctx, const int64_t* off_d, int n_utts, int32_t* out_d) {
-    hipLaunchKernelGGL(lsr_utt_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, off_d, out_d);
+int lsr_launch_utt_index(lsr_ctx* ctx, const int64_t* off_d, int n_utts, int64_t total, int32_t* out_d) {
+    hipLaunchKernelGGL(lsr_utt_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, off_d, total, out_d);
     LSR_LAUNCH_CHECK(ctx, "lsr_utt_index_kernel");
     return LSR_OK;
 }
@@ -285,8 +289,8 @@ __global__ __launch_bounds__(256) void lsr_remux_kernel(const int8_t* __restrict
                                                         const int64_t* __restrict__ chain_off,
                                                         const int32_t* __restrict__ chain_state,
                                                         const int32_t* __restrict__ chain_word,
-                                                        const int32_t* __restrict__ frame_utt, int64_t total_frames,
-                                                        int n_states, int drop_last_run, int use_lds,
+                                                        const int32_t* __restrict__ frame_utt, int n_utts,
+                                                        int64_t total_frames, int n_states, int drop_last_run, int use_lds,
                                                         int32_t* __restrict__ slots,
                                                         unsigned long long* __restrict__ trans) {
     extern __shared__ unsigned int local_trans[];
@@ -300,10 +304,14 @@ __global__ __launch_bounds__(256) void lsr_remux_kernel(const int8_t* __restrict
         const int64_t f = f0 + it * 256 + threadIdx.x;
         if (f >= total_frames) break;
         const int b = frame_utt[f];
+        if (b < 0 || b >= n_utts) {         // a frame outside every utterance's range
+            slots[f] = -1;
+            continue;
+        }
         const int64_t c0 = chain_off[b], n_chain = chain_off[b + 1] - c0;
         const int64_t last = frame_off[b + 1] - 1;
         const int p = paths[f];
-        if (p < 0 || p >= n_chain) {        // only a one-frame utterance has no back-pointer (-1)
+        if (p < 0 || p >= n_chain || last >= total_frames) {        // only a one-frame utterance has no back-pointer (-1)
             slots[f] = -1;
             continue;
         }
@@ -349,13 +357,15 @@ extern "C" int lsr_remux_slots(lsr_ctx* ctx, const int8_t* paths_d, const int64_
     if (rc) return rc;
     int32_t* frame_utt = (int32_t*)ctx->ws_frame_utt.ptr;
     LSR_HIP_CHECK(ctx, hipMemsetAsync(trans_d, 0, (size_t)n_states * n_states * sizeof(int64_t), ctx->stream));
-    hipLaunchKernelGGL(lsr_utt_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, frame_off_d, frame_utt);
+    // frames that no utterance covers (inconsistent offsets) keep -1 and are skipped by the re-mux kernel
+    LSR_HIP_CHECK(ctx, hipMemsetAsync(frame_utt, 0xFF, (size_t)total_frames * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(lsr_utt_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, frame_off_d, total_frames, frame_utt);
     LSR_LAUNCH_CHECK(ctx, "lsr_utt_index_kernel");
     const int use_lds = n_states <= RM_LDS_STATES;
     const size_t lds = use_lds ? (size_t)n_states * n_states * sizeof(unsigned int) : 0;
     hipLaunchKernelGGL(lsr_remux_kernel, dim3((unsigned)((total_frames + RM_FRAMES - 1) / RM_FRAMES)), dim3(256), lds,
-                       ctx->stream, paths_d, frame_off_d, chain_off_d, chain_state_d, chain_word_d, frame_utt, total_frames,
-                       n_states, drop_last_run, use_lds, slots_d, (unsigned long long*)trans_d);
+                       ctx->stream, paths_d, frame_off_d, chain_off_d, chain_state_d, chain_word_d, frame_utt, n_utts,
+                       total_frames, n_states, drop_last_run, use_lds, slots_d, (unsigned long long*)trans_d);
     LSR_LAUNCH_CHECK(ctx, "lsr_remux_kernel");
     return LSR_OK;
 }
