@@ -14,7 +14,11 @@
  *   - "_d" parameters are DEVICE pointers owned by the caller (e.g. torch tensors); all other
  *     pointers are host pointers.  Nothing is retained after a call returns except what
  *     lsr_model_upload / lsr_loop_graph_upload copy to the device.
- *   - ragged batches are one concatenated buffer plus int64 offsets[B+1] (offsets[0] = 0).
+ *   - ragged batches are one concatenated buffer plus int64 offsets[B+1] (offsets[0] = 0,
+ *     non-decreasing, offsets[B] = the stated total).  Offsets live on the device and are not
+ *     checked on the host; the kernels clamp them to the stated totals, so inconsistent offsets give
+ *     meaningless results in the caller's own outputs, not writes outside the library's workspace.
+ *     Audio and feature buffers are read through the sample / frame offsets as given.
  *   - kernels are enqueued on the context's stream (lsr_set_stream, default: the null stream);
  *     calls are asynchronous with respect to the host unless stated otherwise.
  *   - internal workspace grows on demand (hipMalloc) and is reused; a steady-state loop over
