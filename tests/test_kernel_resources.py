@@ -1,0 +1,44 @@
+"""Register and occupancy budget of the two hot kernels, read from the compiler's resource remarks (no GPU needed).
+
+Both kernels are tuned to three wavefronts per SIMD without spills; for the mel power kernel a spill is not a small
+loss: scratch reloads share the in-order memory counter with the sample prefetch and stall on it.  A toolchain or
+source change that breaks the budget should fail here, not show up as a slower bench line."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "cs-304-speech-recognition-code_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _resources(source, tmp_path):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Rpass-analysis=kernel-resource-usage", "-c",
+           os.path.join(CSRC, source), "-o", str(tmp_path / "out.o")]
+    err = subprocess.run(cmd, check=True, capture_output=True, text=True).stderr
+    out, name = {}, None
+    for line in err.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and name:
+            out[name][m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+@pytest.mark.parametrize("source,pattern,max_vgprs", [("lsr_mfcc.hip", "lsr_mel_power_kernel", 168),
+                                                      ("lsr_emission.hip", "lsr_emission_kernelILb1ELb0E", 168)])
+def test_three_wavefronts_per_simd_without_spills(tmp_path, source, pattern, max_vgprs):
+    kernels = {k: v for k, v in _resources(source, tmp_path).items() if pattern in k}
+    assert kernels, "kernel not found in the compiler remarks"
+    for name, r in kernels.items():
+        assert r["ScratchSize"] == 0, (name, r)
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= max_vgprs, (name, r)
+        assert r["Occupancy"] >= 3, (name, r)
