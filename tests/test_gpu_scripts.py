@@ -60,3 +60,30 @@ def test_train_test_sweep(tmp_path):
     with pytest.raises(HiddenMarkovModelTrainable.HMMTrainMeanFail):
         project6.main(strings, str(tmp_path / "cache"), max_iterations=3)
     assert len(os.listdir(str(tmp_path / "cache" / "big_model_speech_only_continuous_2"))) == 12
+
+
+def test_flows_without_silence_model(tmp_path):
+    """project3_train -> project5_test_1digit / project5_test_ndigits_no_sil / project5_find_trans_ndigits_no_sil: the
+    eleven digit models trained on the raw one-digit clips (leading and trailing silence included), decoded in a free
+    loop of 55 states without the silence word."""
+    corpus = load("make_synthetic_corpus").write_corpus(str(tmp_path / "corpus"))
+    models = load("project3_train").main(corpus, str(tmp_path / "cache"), max_iterations=30)
+    assert models.endswith("big_model_no_silence")
+    assert sorted(os.listdir(models)) == ["1", "2", "3", "4", "5", "6", "7", "8", "9", "O", "Z"]
+    truth, prediction, accuracy = load("project5_test_1digit").main(corpus, models)
+    assert len(truth) == 11 * 12 and accuracy >= 0.9, accuracy
+    no_sil = load("project5_test_ndigits_no_sil")
+    for split in ("train", "test"):
+        truth, prediction, accuracy = no_sil.main(corpus, models, n=2, split=split)
+        assert len(truth) == 12 and all(set(p) <= set("123456789OZ") for p in prediction)
+        assert accuracy >= 0.75, (split, list(zip(truth, prediction)))
+    penalties, results = load("project5_find_trans_ndigits_no_sil").main(corpus, models, penalties=[0, -250, -1e5])
+    assert penalties == [0, -250, -1e5] and len(results) == 3 and results[1] >= 75.0 and results[2] == 0.0
+    # the sweep decodes exactly what a decoder with that penalty decodes
+    from loe_speech_recognition_amd import MFCC, TI_DIGITS_LABELS, HiddenMarkovModelInference, TIDigits
+    decoder = HiddenMarkovModelInference.from_folder(models, list(TI_DIGITS_LABELS))
+    clips = TIDigits(corpus, isLazyLoading=True).train_dataset.get_all_n_digits(2)
+    mfccs = MFCC.batch([s for signals in clips.values() for s in signals[:5]], sample_rate=16000)
+    rows = decoder.predict_sweep(mfccs, [-250])
+    decoder._log_transition_probability_between_words = -250
+    assert rows[0] == decoder.predict_batch(mfccs)
