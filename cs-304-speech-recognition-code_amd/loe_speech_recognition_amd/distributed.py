@@ -194,5 +194,6 @@ def gather_label_records(labels, n_labels, n_total: int):
 
 
 def records_to_strings(labels: np.ndarray, n_labels: np.ndarray, names: Sequence[str]) -> List[str]:
-    cap = labels.shape[1]
-    return ["".join(names[w] for w in labels[i, :min(int(n_labels[i]), cap)]) for i in range(labels.shape[0])]
+    from . import _native
+
+    return _native.records_to_strings(labels, n_labels, names)

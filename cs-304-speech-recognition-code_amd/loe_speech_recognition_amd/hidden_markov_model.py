@@ -463,7 +463,7 @@ class HiddenMarkovModelInference:
         names = self._model_boundaries._labels
         lab = labels.cpu().numpy()
         cnt = n_labels.cpu().numpy()
-        out = ["".join(names[w] for w in lab[i, :min(int(cnt[i]), label_cap)]) for i in range(fb.n)]
+        out = _native.records_to_strings(lab, cnt, names)
         over = np.nonzero(cnt > label_cap)[0]
         if over.shape[0]:                       # more words than the fixed-width record holds: re-read from the path
             _, paths, _, _ = eng.decode_loop(fb, want_paths=True, label_cap=label_cap)
@@ -498,7 +498,7 @@ class HiddenMarkovModelInference:
         lab, cnt = labels.cpu().numpy(), n_labels.cpu().numpy()
         out = []
         for i, between in enumerate(betweens):
-            row = ["".join(names[w] for w in lab[i, b, :min(int(cnt[i, b]), label_cap)]) for b in range(fb.n)]
+            row = _native.records_to_strings(lab[i], cnt[i], names)
             if (cnt[i] > label_cap).any():      # more words than a record holds: decode that penalty alone, from paths
                 saved = self._log_transition_probability_between_words
                 self._log_transition_probability_between_words = between
@@ -509,27 +509,33 @@ class HiddenMarkovModelInference:
             out.append(row)
         return out
 
-    def recognize_audio(self, signals, label_cap: int = 32, streamed: bool = False, chunk_samples: int = 0,
+    STREAM_FROM_SAMPLES = 4 << 20        # host batches of at least this many samples go through the upload pipeline
+
+    def recognize_audio(self, signals, label_cap: int = 32, streamed: Optional[bool] = None, chunk_samples: int = 0,
                         threads: int = 0) -> List[str]:
         """Audio in, label strings out: MFCC + decode without the features leaving the device
         (the per-utterance work of scripts/project5_test_ndigits_with_sil.py:64-77).
         ``streamed=True`` takes host arrays (int16 as read from a wav file, or float32) through the
         chunked upload pipeline: pinned staging, asynchronous copies overlapped with the decoding of
-        earlier chunks; the strings are the same as with one resident batch."""
+        earlier chunks; the strings are the same as with one resident batch.  By default (``None``) host
+        batches of 4 Mi samples or more are streamed and smaller ones, where one synchronous copy is the
+        shorter way, are not."""
         eng = self._bind()
         names = self._model_boundaries._labels
-        if streamed and not isinstance(signals, _native.AudioBatch):
+        on_host = not isinstance(signals, _native.AudioBatch)
+        if streamed is None:
+            streamed = on_host and sum(int(np.shape(s)[0]) for s in signals) >= self.STREAM_FROM_SAMPLES
+        if streamed and on_host:
             _, lab, cnt = eng.recognize_host(signals, label_cap=label_cap, chunk_samples=chunk_samples, threads=threads)
             if (cnt > label_cap).any():
-                return self.recognize_audio(signals, label_cap=label_cap)
-            return ["".join(names[w] for w in lab[i, :int(cnt[i])]) for i in range(lab.shape[0])]
-        ab = signals if isinstance(signals, _native.AudioBatch) else eng.audio_batch(signals)
+                return self.recognize_audio(signals, label_cap=label_cap, streamed=False)
+            return _native.records_to_strings(lab, cnt, names)
+        ab = signals if not on_host else eng.audio_batch(signals)
         _, _, labels, n_labels = eng.recognize(ab, want_paths=False, label_cap=label_cap)
         cnt = n_labels.cpu().numpy()
         if (cnt > label_cap).any():
             return self.predict_batch(eng.mfcc(ab), label_cap=label_cap)
-        lab = labels.cpu().numpy()
-        return ["".join(names[w] for w in lab[i, :int(cnt[i])]) for i in range(ab.n)]
+        return _native.records_to_strings(labels.cpu().numpy(), cnt, names)
 
     def _viterbi(self, observation_sequence: np.ndarray) -> Tuple[np.float32, np.ndarray]:
         return self.viterbi_batch([observation_sequence])[0]

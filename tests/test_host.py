@@ -157,3 +157,22 @@ def test_synthetic_models_load_and_are_positive_definite():
     sig, truth = synthetic.utterance(3, 0, 4)
     sig2, truth2 = synthetic.utterance(3, 0, 4)
     assert truth == truth2 and np.array_equal(sig, sig2) and sig.dtype == np.float32
+
+
+def test_records_to_strings_vectorised_path_equals_the_loop():
+    """Fixed-width label records -> strings: the one-character fast path, multi-character names, counts beyond the
+    record width, the -1 sentinel and padding bytes."""
+    from loe_speech_recognition_amd import _native
+
+    rng = np.random.default_rng(0)
+    names = list("123456789OSZ")
+    lab = rng.integers(0, 12, size=(500, 16)).astype(np.uint8)
+    cnt = rng.integers(-1, 20, size=500).astype(np.int32)
+    lab[5, 3:] = 0xFF
+    cnt[5] = 3
+    want = ["".join(names[w] for w in lab[i, :max(0, min(int(cnt[i]), 16))]) for i in range(500)]
+    assert _native.records_to_strings(lab, cnt, names) == want
+    long_names = ["one", "two"] + names[2:]
+    want = ["".join(long_names[w] for w in lab[i, :max(0, min(int(cnt[i]), 16))]) for i in range(500)]
+    assert _native.records_to_strings(lab, cnt, long_names) == want
+    assert _native.records_to_strings(np.zeros((0, 4), np.uint8), np.zeros(0, np.int32), names) == []

@@ -22,3 +22,11 @@ f1 = [MFCC(s, 16000).feature_vector.T for s in one]
 T("ModelCollection.predict(features)", lambda i=0: mc.predict(f1[i % 64]))
 T("recognize_audio([clip])", lambda i=0: inf.recognize_audio([sigs[i % 64]])[0])
 T("recognize_audio(64 clips)", lambda: inf.recognize_audio(sigs), n=20)
+# a bench-sized batch from host arrays to Python strings (the upload pipeline is chosen automatically)
+import bench  # noqa: E402
+
+big, _ = bench.generate(0, 10000, 8)
+big16 = [np.round(c).astype(np.int16) for c in big]
+T("recognize_audio(10 000 float32 clips)", lambda: inf.recognize_audio(big), n=5)
+T("recognize_audio(10 000 int16 clips)", lambda: inf.recognize_audio(big16), n=5)
+T("recognize_audio(10 000, streamed=False)", lambda: inf.recognize_audio(big, streamed=False), n=3)
