@@ -273,11 +273,19 @@ class HiddenMarkovModelTrainable(HiddenMarkovModel):
     def from_data(cls, label: str, mfccs: List[np.ndarray], num_of_states: int = 5, max_iterations: int = 100,
                   isMultiProcessingTraining: bool = True, isTqdm: bool = True):
         """Segmental k-means for one word (hidden_markov_model.py:233-281).  The utterances are
-        uploaded once; every iteration is one batched alignment plus one statistics reduction."""
+        uploaded once; every iteration is one batched alignment plus one statistics reduction.
+        ``mfccs`` may also be a FeatureBatch that is already on the device (MFCC.batch_device)."""
         model = cls(label, isMultiProcessing=isMultiProcessingTraining, isTqdm=isTqdm)
-        model._means, model._covariances, model._transition_probs = model._init_parameters(mfccs[0], num_of_states)
+        if isinstance(mfccs, _native.FeatureBatch):
+            fb = mfccs
+            first = fb.feats[:int(fb.lengths[0])].cpu().numpy()
+        else:
+            fb = None
+            first = mfccs[0]
+        model._means, model._covariances, model._transition_probs = model._init_parameters(first, num_of_states)
         model._update_inference_weights()
-        fb = _native.get_engine().feature_batch(mfccs)
+        if fb is None:
+            fb = _native.get_engine().feature_batch(mfccs)
         bar = tqdm(desc=f"Train {model.label} model", total=max_iterations, position=1, disable=not model.isTqdm)
         for _ in range(max_iterations):
             try:

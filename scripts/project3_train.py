@@ -13,7 +13,7 @@ def main(corpus: str, cache: str, model_name: str = "big_model_no_silence", max_
     out = os.path.join(cache, model_name)
     train = TIDigits(corpus, isLazyLoading=True).train_dataset
     for label in TI_DIGITS_LABELS:
-        mfccs = MFCC.batch(train[label], sample_rate=16000)
+        mfccs = MFCC.batch_device(train[label], sample_rate=16000)        # features stay on the device
         HiddenMarkovModelTrainable.from_data(label, mfccs, num_of_states=5, max_iterations=max_iterations,
                                              isMultiProcessingTraining=True, isTqdm=False).save(out)
     return out

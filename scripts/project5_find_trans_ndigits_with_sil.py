@@ -15,7 +15,7 @@ def main(corpus: str, model_folder: str, n: int = 2, per_label: int = 5, penalti
     decoder = HiddenMarkovModelInference.from_folder(model_folder, list(TI_DIGITS_LABELS) + ["S"])
     clips = TIDigits(corpus, isLazyLoading=True).train_dataset.get_all_n_digits(n)
     truth = [label for label, signals in clips.items() for _ in signals[:per_label]]
-    mfccs = MFCC.batch([s for signals in clips.values() for s in signals[:per_label]], sample_rate=16000)
+    mfccs = MFCC.batch_device([s for signals in clips.values() for s in signals[:per_label]], sample_rate=16000)
     results = []
     for value, row in zip(penalties, decoder.predict_sweep(mfccs, penalties)):
         accuracy = sum(t == p for t, p in zip(truth, row)) / len(truth) * 100

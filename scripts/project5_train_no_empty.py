@@ -17,11 +17,11 @@ def main(corpus: str, cache: str, model_name: str = "big_model_speech_only", max
     stripper = SignalSeparation(sample_rate=16000, speech_high_threshold=0.06, speech_low_threshold=0.01)
     for label in TI_DIGITS_LABELS:
         speech = stripper.remove_empty_batch(train[label])
-        mfccs = MFCC.batch(speech, sample_rate=16000)
+        mfccs = MFCC.batch_device(speech, sample_rate=16000)                # features stay on the device
         HiddenMarkovModelTrainable.from_data(label, mfccs, num_of_states=5, max_iterations=max_iterations,
                                              isTqdm=False).save(out)
     noise = [n for n in stripper.get_all_noises() if n.shape[0] >= 9 * 160]       # MFCC needs 9 frames
-    HiddenMarkovModelTrainable.from_data("S", MFCC.batch(noise, sample_rate=16000), num_of_states=3,
+    HiddenMarkovModelTrainable.from_data("S", MFCC.batch_device(noise, sample_rate=16000), num_of_states=3,
                                          max_iterations=max_iterations, isTqdm=False).save(out)
     return out
 
