@@ -138,3 +138,31 @@ def test_random_alignment_chain(seed):
         score, path, _ = O.viterbi_chain_fast(emis, band)
         assert out[i][0] == score or (np.isnan(out[i][0]) and np.isnan(score)), (seed, i, out[i][0], score)
         assert np.array_equal(out[i][1], path), (seed, i)
+
+
+def test_utterance_longer_than_64k_frames_and_the_limit():
+    """One utterance of 70 000 frames (its path needs more than 64 KiB of LDS, a size the launcher has to ask for)
+    next to a short one; beyond the LDS of a compute unit the decoder refuses with a clear error."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, _native
+
+    rng = np.random.default_rng(77)
+    words = _graph(rng, 40, tied=False)
+    inf = HiddenMarkovModelInference.from_models([trainable(*w) for w in words])
+    inf._log_transition_probability_between_words = -20
+    ltp, gauss, bounds = O.stack_models([O.WordModelRef(*w) for w in words])
+    S = bounds.num_states
+    band = O.band_from_ltp(ltp, S, [bounds.find_lower(s) for s in range(S)])
+    xs = [(1.5 * rng.standard_normal((70000, 39))).astype(np.float32), (1.5 * rng.standard_normal((30, 39))).astype(np.float32)]
+    vit = inf.viterbi_batch(xs)
+    strings = inf.predict_batch(xs, label_cap=32)
+    eng = _native.get_engine()
+    inf._bind()
+    ll = eng.emission(eng.feature_batch(xs)).cpu().numpy()
+    t0 = 0
+    for i, x in enumerate(xs):
+        score, path = O.viterbi_loop_fast(ll[t0:t0 + x.shape[0], :S], band, bounds.lower, bounds.upper, -20)
+        t0 += x.shape[0]
+        assert vit[i][0] == score and np.array_equal(vit[i][1], path), i
+        assert strings[i] == "".join(bounds.get_labels(path)), i            # the long one overflows its record
+    with pytest.raises(_native.NativeError, match="frame"):
+        inf.viterbi_batch([np.zeros((170000, 39), np.float32)])
