@@ -368,7 +368,7 @@ def main():
     # the path as a caller with host arrays sees it: chunked, pinned, overlapped upload (lsr_recognize_host)
     h2d = None
     if world == 1 and not args.no_h2d:
-        h2d = {"pageable_synchronous_upload_s": round(upload_s, 4)}
+        h2d = {"resident_batch_upload_s": round(upload_s, 4)}      # Engine.audio_batch: lsr_upload_host, first call
         h_steps = max(3, min(args.steps, 5))
         for tag, clips in (("float32", sigs), ("int16", [np.round(c).astype(np.int16) for c in sigs])):
             nbytes = float(sum(c.nbytes for c in clips))

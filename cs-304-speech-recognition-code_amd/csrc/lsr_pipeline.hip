@@ -73,15 +73,16 @@ struct lsr_pool {
 
 struct lsr_pipe_slot {
     void* pinned = nullptr;          // staging: [audio bytes | sample_off int64[n+1] | frame_off int64[n+1]]
-    void* device = nullptr;          // same layout on the device
-    size_t bytes = 0;
+    void* device = nullptr;          // same layout on the device (lsr_recognize_host only)
+    size_t bytes = 0, device_bytes = 0;
     hipEvent_t copied = nullptr;     // upload of the slot's chunk has finished
-    hipEvent_t decoded = nullptr;    // kernels that read the slot have finished
+    hipEvent_t decoded = nullptr;    // whatever reads the slot (kernels, or the copy itself) has finished
     bool busy = false;
 };
 
 struct lsr_pipeline {
     hipStream_t copy_stream = nullptr;
+    hipEvent_t fence = nullptr;      // position of the context's stream when an upload starts
     lsr_pipe_slot slot[PIPE_SLOTS];
     lsr_buffer out_dev;              // [scores f32[B] | n_labels i32[B] | labels u8[B][cap]]
     void* out_pinned = nullptr;
@@ -100,7 +101,7 @@ static void pipe_free_slot(lsr_pipe_slot& s) {
     if (s.pinned) (void)hipHostFree(s.pinned);
     if (s.device) (void)hipFree(s.device);
     s.pinned = s.device = nullptr;
-    s.bytes = 0;
+    s.bytes = s.device_bytes = 0;
 }
 
 void lsr_pipeline_destroy(lsr_ctx* ctx) {
@@ -113,6 +114,7 @@ void lsr_pipeline_destroy(lsr_ctx* ctx) {
     }
     if (p->out_dev.ptr) (void)hipFree(p->out_dev.ptr);
     if (p->out_pinned) (void)hipHostFree(p->out_pinned);
+    if (p->fence) (void)hipEventDestroy(p->fence);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     delete p->pool;
     delete p;
@@ -124,6 +126,7 @@ static int pipe_get(lsr_ctx* ctx, int threads, lsr_pipeline** out) {
         lsr_pipeline* p = new lsr_pipeline();
         ctx->pipeline = p;
         LSR_HIP_CHECK(ctx, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        LSR_HIP_CHECK(ctx, hipEventCreateWithFlags(&p->fence, hipEventDisableTiming));
         for (auto& s : p->slot) {
             LSR_HIP_CHECK(ctx, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
             LSR_HIP_CHECK(ctx, hipEventCreateWithFlags(&s.decoded, hipEventDisableTiming));
@@ -139,13 +142,32 @@ static int pipe_get(lsr_ctx* ctx, int threads, lsr_pipeline** out) {
     return LSR_OK;
 }
 
-static int pipe_reserve_slot(lsr_ctx* ctx, lsr_pipe_slot& s, size_t bytes) {
-    if (bytes <= s.bytes) return LSR_OK;
-    pipe_free_slot(s);
+// staging memory is only resized or handed to a new chunk when the copy or kernels that use it have finished
+static int pipe_wait_idle(lsr_ctx* ctx, lsr_pipeline* p) {
+    for (auto& s : p->slot)
+        if (s.busy) {
+            LSR_HIP_CHECK(ctx, hipEventSynchronize(s.decoded));
+            s.busy = false;
+        }
+    return LSR_OK;
+}
+
+static int pipe_reserve_slot(lsr_ctx* ctx, lsr_pipe_slot& s, size_t bytes, bool with_device) {
     const size_t want = bytes + bytes / 8 + 4096;
-    LSR_HIP_CHECK(ctx, hipHostMalloc(&s.pinned, want, hipHostMallocDefault));
-    LSR_HIP_CHECK(ctx, hipMalloc(&s.device, want));
-    s.bytes = want;
+    if (bytes > s.bytes) {
+        if (s.pinned) LSR_HIP_CHECK(ctx, hipHostFree(s.pinned));
+        s.pinned = nullptr;
+        s.bytes = 0;
+        LSR_HIP_CHECK(ctx, hipHostMalloc(&s.pinned, want, hipHostMallocDefault));
+        s.bytes = want;
+    }
+    if (with_device && bytes > s.device_bytes) {
+        if (s.device) LSR_HIP_CHECK(ctx, hipFree(s.device));
+        s.device = nullptr;
+        s.device_bytes = 0;
+        LSR_HIP_CHECK(ctx, hipMalloc(&s.device, want));
+        s.device_bytes = want;
+    }
     return LSR_OK;
 }
 
@@ -209,8 +231,9 @@ extern "C" int lsr_recognize_host(lsr_ctx* ctx, const void* const* clips, const 
     if (max_frames_chunk > ((int64_t)1 << 31) - 64)
         return lsr_fail(ctx, LSR_ERR_LIMIT, "lsr_recognize_host: chunk of %lld frames", (long long)max_frames_chunk);
     // everything that can grow is sized before the pipeline starts, so no chunk stalls on an allocation
+    if ((rc = pipe_wait_idle(ctx, p))) return rc;
     for (int s = 0; s < PIPE_SLOTS && s < n_chunks; ++s)
-        if ((rc = pipe_reserve_slot(ctx, p->slot[s], max_bytes))) return rc;
+        if ((rc = pipe_reserve_slot(ctx, p->slot[s], max_bytes, true))) return rc;
     const size_t out_bytes = (size_t)n_utts * (sizeof(float) + sizeof(int32_t) + (size_t)label_cap);
     if ((rc = lsr_reserve(ctx, &p->out_dev, out_bytes, "pipeline outputs"))) return rc;
     if (out_bytes > p->out_pinned_bytes) {
@@ -305,5 +328,131 @@ extern "C" int lsr_recognize_host_timing(lsr_ctx* ctx, double* seconds4, int* n_
     seconds4[2] = ctx->pipeline->t_submit;
     seconds4[3] = ctx->pipeline->t_drain;
     if (n_chunks) *n_chunks = ctx->pipeline->last_chunks;
+    return LSR_OK;
+}
+
+// Host arrays -> one device buffer, back to back: the upload half of the pipeline above without the decoding.
+// Worker threads pack the arrays of a chunk into pinned staging memory (no concatenation on the caller's side),
+// the copy stream moves chunk after chunk while later chunks are packed.  The copies are ordered after everything
+// the context's stream has queued so far (the destination may be memory that earlier kernels still use) and the
+// context's stream waits for the last copy, so kernels launched afterwards see the data; the call itself returns
+// when every array has been packed, not when the last copy has landed.
+extern "C" int lsr_upload_host(lsr_ctx* ctx, const void* const* arrays, const int64_t* n_elems, int64_t n_arrays,
+                               int elem_bytes, int64_t chunk_bytes, int n_threads, void* dst_d) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!arrays || !n_elems || !dst_d) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_upload_host: null pointer");
+    if (n_arrays < 1 || n_arrays > INT32_MAX || elem_bytes < 1 || elem_bytes > 16)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_upload_host: bad sizes");
+    if (chunk_bytes <= 0) chunk_bytes = (int64_t)96 << 20;
+    if (n_threads <= 0) n_threads = 8;
+    if (n_threads > 64) n_threads = 64;
+    for (int64_t i = 0; i < n_arrays; ++i)
+        if (n_elems[i] < 0 || (n_elems[i] > 0 && !arrays[i]))
+            return lsr_fail(ctx, LSR_ERR_ARG, "lsr_upload_host: array %lld is null or has a negative size", (long long)i);
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    lsr_pipeline* p = nullptr;
+    int rc = pipe_get(ctx, n_threads, &p);
+    if (rc) return rc;
+    const int n = (int)n_arrays;
+    std::vector<int64_t> off(n + 1);                      // byte offset of every array in the destination
+    off[0] = 0;
+    for (int i = 0; i < n; ++i) off[i + 1] = off[i] + n_elems[i] * elem_bytes;
+    std::vector<int> first;                                // chunks of consecutive arrays (at least one per chunk)
+    first.push_back(0);
+    for (int i = 0; i < n; ++i)
+        if (off[i] - off[first.back()] > 0 && off[i + 1] - off[first.back()] > chunk_bytes) first.push_back(i);
+    first.push_back(n);
+    const int n_chunks = (int)first.size() - 1;
+    size_t max_bytes = 0;
+    for (int c = 0; c < n_chunks; ++c) max_bytes = std::max(max_bytes, (size_t)(off[first[c + 1]] - off[first[c]]));
+    bool grow = false;
+    for (int s = 0; s < PIPE_SLOTS && s < n_chunks; ++s) grow = grow || max_bytes > p->slot[s].bytes;
+    if (grow && (rc = pipe_wait_idle(ctx, p))) return rc;
+    for (int s = 0; s < PIPE_SLOTS && s < n_chunks; ++s)
+        if ((rc = pipe_reserve_slot(ctx, p->slot[s], max_bytes, false))) return rc;
+    LSR_HIP_CHECK(ctx, hipEventRecord(p->fence, ctx->stream));
+    LSR_HIP_CHECK(ctx, hipStreamWaitEvent(p->copy_stream, p->fence, 0));
+    hipEvent_t last = nullptr;
+    for (int c = 0; c < n_chunks; ++c) {
+        lsr_pipe_slot& s = p->slot[c % PIPE_SLOTS];
+        if (s.busy) {
+            LSR_HIP_CHECK(ctx, hipEventSynchronize(s.decoded));
+            s.busy = false;
+        }
+        const int a0 = first[c], na = first[c + 1] - a0;
+        const int64_t base = off[a0], bytes = off[a0 + na] - base;
+        if (bytes == 0) continue;
+        unsigned char* stage = (unsigned char*)s.pinned;
+        const int tasks = std::min(na, 4 * n_threads);
+        std::vector<int> cut(tasks + 1);
+        for (int t = 0, a = 0; t <= tasks; ++t) {
+            const int64_t goal = bytes * t / tasks;
+            while (a < na && off[a0 + a] - base < goal) ++a;
+            cut[t] = t == tasks ? na : a;
+        }
+        p->pool->parallel_for(tasks, [&](int t) {
+            for (int i = a0 + cut[t]; i < a0 + cut[t + 1]; ++i)
+                if (n_elems[i]) memcpy(stage + (off[i] - base), arrays[i], (size_t)(off[i + 1] - off[i]));
+        });
+        LSR_HIP_CHECK(ctx, hipMemcpyAsync((unsigned char*)dst_d + base, s.pinned, (size_t)bytes, hipMemcpyHostToDevice,
+                                          p->copy_stream));
+        LSR_HIP_CHECK(ctx, hipEventRecord(s.decoded, p->copy_stream));      // the slot is free again after its copy
+        s.busy = true;
+        last = s.decoded;
+    }
+    if (last) LSR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, last, 0));
+    return LSR_OK;
+}
+
+// One device buffer -> host memory: the copy stream moves chunk after chunk into pinned staging memory while worker
+// threads copy the previous chunk to its place in the destination (a pageable destination written by one
+// synchronous copy reaches a fraction of the link's rate, and fresh pages are faulted in by several threads here).
+// The copies are ordered after everything queued on the context's stream; the call returns when dst is complete.
+extern "C" int lsr_download_host(lsr_ctx* ctx, const void* src_d, int64_t bytes, void* dst, int64_t chunk_bytes,
+                                 int n_threads) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (!src_d || !dst || bytes < 0) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_download_host: bad argument");
+    if (bytes == 0) return LSR_OK;
+    if (chunk_bytes <= 0) chunk_bytes = (int64_t)32 << 20;
+    if (n_threads <= 0) n_threads = 8;
+    if (n_threads > 64) n_threads = 64;
+    LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    lsr_pipeline* p = nullptr;
+    int rc = pipe_get(ctx, n_threads, &p);
+    if (rc) return rc;
+    if ((rc = pipe_wait_idle(ctx, p))) return rc;
+    const int64_t n_chunks = (bytes + chunk_bytes - 1) / chunk_bytes;
+    const size_t slot_bytes = (size_t)std::min(bytes, chunk_bytes);
+    for (int s = 0; s < 2 && s < n_chunks; ++s)
+        if ((rc = pipe_reserve_slot(ctx, p->slot[s], slot_bytes, false))) return rc;
+    LSR_HIP_CHECK(ctx, hipEventRecord(p->fence, ctx->stream));
+    LSR_HIP_CHECK(ctx, hipStreamWaitEvent(p->copy_stream, p->fence, 0));
+    auto span = [&](int64_t c, int64_t* off) {
+        *off = c * chunk_bytes;
+        return std::min(chunk_bytes, bytes - *off);
+    };
+    for (int64_t c = 0; c <= n_chunks; ++c) {
+        if (c < n_chunks) {                                  // chunk c travels into slot c % 2 ...
+            int64_t off;
+            const int64_t len = span(c, &off);
+            lsr_pipe_slot& s = p->slot[c % 2];
+            LSR_HIP_CHECK(ctx, hipMemcpyAsync(s.pinned, (const unsigned char*)src_d + off, (size_t)len, hipMemcpyDeviceToHost,
+                                              p->copy_stream));
+            LSR_HIP_CHECK(ctx, hipEventRecord(s.copied, p->copy_stream));
+        }
+        if (c >= 1) {                                        // ... while chunk c - 1 is copied to its destination
+            int64_t off;
+            const int64_t len = span(c - 1, &off);
+            lsr_pipe_slot& s = p->slot[(c - 1) % 2];
+            LSR_HIP_CHECK(ctx, hipEventSynchronize(s.copied));
+            const int tasks = (int)std::min<int64_t>(4 * n_threads, (len + 65535) / 65536);
+            const unsigned char* stage = (const unsigned char*)s.pinned;
+            unsigned char* out = (unsigned char*)dst + off;
+            p->pool->parallel_for(tasks, [&](int t) {
+                const int64_t a = len * t / tasks, b = len * (t + 1) / tasks;
+                memcpy(out + a, stage + a, (size_t)(b - a));
+            });
+        }
+    }
     return LSR_OK;
 }

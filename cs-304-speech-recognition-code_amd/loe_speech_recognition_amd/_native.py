@@ -62,6 +62,8 @@ def _declare(lib) -> None:
         "lsr_recognize_batch_noalloc": (c_int, [P, P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_recognize_host": (c_int, [P, P, P, c_int, c_int, c_int64, c_int, P, P, P, c_int]),
         "lsr_recognize_host_timing": (c_int, [P, POINTER(c_double), POINTER(c_int)]),
+        "lsr_upload_host": (c_int, [P, P, P, c_int64, c_int, c_int64, c_int, P]),
+        "lsr_download_host": (c_int, [P, P, c_int64, P, c_int64, c_int]),
         "lsr_shard_bounds": (None, [c_int64, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
         "lsr_comm_get_unique_id": (c_int, [P, P]),
         "lsr_comm_init": (c_int, [P, P, c_int, c_int]),
@@ -102,7 +104,7 @@ EXPORTED_SYMBOLS = [
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
     "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures", "lsr_separation_scan",
     "lsr_gather_segments", "lsr_decode_loop_sweep", "lsr_recognize_batch_noalloc",
-    "lsr_recognize_host", "lsr_recognize_host_timing", "lsr_shard_bounds", "lsr_comm_get_unique_id", "lsr_comm_init",
+    "lsr_recognize_host", "lsr_recognize_host_timing", "lsr_upload_host", "lsr_download_host", "lsr_shard_bounds", "lsr_comm_get_unique_id", "lsr_comm_init",
     "lsr_comm_destroy", "lsr_allgather_labels", "lsr_allreduce_stats", "lsr_label_record_bytes",
     "lsr_host_pack_label_records", "lsr_host_unpack_label_records", "lsr_pack_label_records", "lsr_unpack_label_records",
     "lsr_labels_from_paths", "lsr_ll_stride", "lsr_decode_chain_batch_wide",
@@ -238,6 +240,43 @@ class Engine:
         return ms.value, n.value
 
     # -- batches ----------------------------------------------------------------------------------
+    UPLOAD_PIPELINE_BYTES = 16 << 20      # lists of host arrays of at least this size go through lsr_upload_host
+
+    def _upload_list(self, arrays, ndim: int, inner: int):
+        """Device tensor holding the arrays of a list back to back, through the pinned / chunked upload pipeline,
+        or None when the list does not qualify (small, mixed dtypes, non-contiguous): the caller then concatenates
+        on the host and copies once."""
+        if not isinstance(arrays, list) or len(arrays) == 0:
+            return None
+        first = arrays[0]
+        if not isinstance(first, np.ndarray) or first.size * first.itemsize * len(arrays) < self.UPLOAD_PIPELINE_BYTES // 4:
+            return None                                    # cheap estimate before touching every element
+        from . import _lsr_pyhelper as H          # built by the Makefile next to this file
+
+        ptrs = np.empty(len(arrays), np.uint64)
+        sizes = np.empty(len(arrays), np.int64)
+        kind = H.array_table(arrays, ptrs, sizes, ndim, inner)
+        if kind < 0:
+            return None
+        dtype, item = (self.torch.int16, 2) if kind == H.INT16 else (self.torch.float32, 4)
+        total = int(sizes.sum())
+        if total * item < self.UPLOAD_PIPELINE_BYTES:
+            return None
+        out = self.empty((total,), dtype)
+        self._check(self.lib.lsr_upload_host(self.ctx, c_void_p(ptrs.ctypes.data), c_void_p(sizes.ctypes.data), len(arrays),
+                                             item, 0, 0, self._ptr(out)))
+        return out
+
+    def to_host(self, tensor) -> np.ndarray:
+        """NumPy copy of a device tensor; large contiguous ones come back through lsr_download_host (pinned chunks
+        unpacked by threads) instead of one synchronous copy into pageable memory."""
+        nbytes = tensor.numel() * tensor.element_size()
+        if nbytes < self.UPLOAD_PIPELINE_BYTES or not tensor.is_contiguous() or not tensor.is_cuda:
+            return tensor.cpu().numpy()
+        out = np.empty(tuple(tensor.shape), dtype=self.torch.empty(0, dtype=tensor.dtype).numpy().dtype)
+        self._check(self.lib.lsr_download_host(self.ctx, self._ptr(tensor), nbytes, c_void_p(out.ctypes.data), 0, 0))
+        return out
+
     def audio_batch(self, signals: Sequence[np.ndarray]) -> AudioBatch:
         if len(signals) == 0:
             raise ValueError("empty batch")
@@ -245,12 +284,14 @@ class Engine:
         frames = 1 + n // HOP
         if frames.min() < MIN_FRAMES:
             raise ValueError(f"a clip yields {int(frames.min())} frames; the width-9 delta filter needs at least {MIN_FRAMES}")
-        # int16 PCM stays int16 (converted on the device); everything else is float32 like the reference's loader
-        dtype = np.int16 if all(s.dtype == np.int16 for s in signals) else np.float32
-        flat = np.concatenate([np.asarray(s, dtype=dtype) for s in signals])
         soff = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
         foff = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
-        return AudioBatch(self.to_device(flat), self.to_device(soff), self.to_device(foff), n)
+        audio = self._upload_list(signals, 1, 0)
+        if audio is None:
+            # int16 PCM stays int16 (converted on the device); everything else is float32 like the reference's loader
+            dtype = np.int16 if all(s.dtype == np.int16 for s in signals) else np.float32
+            audio = self.to_device(np.concatenate([np.asarray(s, dtype=dtype) for s in signals]))
+        return AudioBatch(audio, self.to_device(soff), self.to_device(foff), n)
 
     def feature_batch(self, feats: Sequence[np.ndarray]) -> FeatureBatch:
         if len(feats) == 0:
@@ -260,9 +301,13 @@ class Engine:
             raise IndexError("index 0 is out of bounds for axis 0 with size 0")
         for f in feats:
             assert f.ndim == 2 and f.shape[1] == DIM
-        flat = np.concatenate([np.asarray(f, dtype=np.float32) for f in feats], axis=0)
         foff = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-        return FeatureBatch(self.to_device(flat), self.to_device(foff), lengths)
+        flat = self._upload_list(feats, 2, DIM)
+        if flat is not None and flat.dtype == self.torch.float32:
+            flat = flat.view(-1, DIM)
+        else:
+            flat = self.to_device(np.concatenate([np.asarray(f, dtype=np.float32) for f in feats], axis=0))
+        return FeatureBatch(flat, self.to_device(foff), lengths)
 
     # -- front-end --------------------------------------------------------------------------------
     def mfcc(self, batch: AudioBatch):

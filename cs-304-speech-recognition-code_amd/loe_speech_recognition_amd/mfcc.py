@@ -62,8 +62,7 @@ class MFCC:
         eng = _native.get_engine()
         ab = eng.audio_batch(signals)
         fb = eng.mfcc(ab)
-        flat = fb.feats.cpu().numpy()
-        return _native.split_ragged(flat, fb.host_off)
+        return _native.split_ragged(eng.to_host(fb.feats), fb.host_off)
 
     @classmethod
     def batch_int16(cls, signals: List[np.ndarray], sample_rate: int = 16000) -> List[np.ndarray]:
@@ -78,7 +77,7 @@ class MFCC:
             raise ValueError("the device front-end is built for 16 kHz audio")
         eng = _native.get_engine()
         fb = eng.mfcc(eng.audio_batch(signals))
-        return _native.split_ragged(fb.feats.cpu().numpy(), fb.host_off)
+        return _native.split_ragged(eng.to_host(fb.feats), fb.host_off)
 
     @classmethod
     def batch_device(cls, signals: List[np.ndarray], sample_rate: int = 16000) -> "_native.FeatureBatch":

@@ -189,6 +189,21 @@ int lsr_recognize_host(lsr_ctx* ctx, const void* const* clips, const int64_t* n_
  * chunk_samples / n_threads; no counterpart in the reference. */
 int lsr_recognize_host_timing(lsr_ctx* ctx, double* seconds4, int* n_chunks);
 
+/* Host arrays -> one device buffer, back to back (the concatenation np.concatenate + one copy would produce): the
+ * upload half of lsr_recognize_host alone, for MFCC.batch / predict_batch style callers whose inputs are lists of
+ * host arrays (mfcc.py:71-84, ti_digits.py:130-134).  arrays[i] holds n_elems[i] elements of elem_bytes bytes;
+ * worker threads pack chunks of about chunk_bytes (0: 96 MiB) into pinned staging memory and a copy stream moves
+ * them while later chunks are packed.  The copies are ordered after the work already queued on the context's
+ * stream and the context's stream waits for the last copy; the call returns when all arrays have been read. */
+int lsr_upload_host(lsr_ctx* ctx, const void* const* arrays, const int64_t* n_elems, int64_t n_arrays,
+                    int elem_bytes, int64_t chunk_bytes, int n_threads, void* dst_d);
+
+/* The other direction, for callers that want the features (or paths) back as host arrays, as MFCC.batch returns them
+ * (mfcc.py:71-84): bytes of device memory to host memory through pinned staging chunks (0: 32 MiB) unpacked by
+ * worker threads while the next chunk travels.  Ordered after the work queued on the context's stream; dst is
+ * complete when the call returns. */
+int lsr_download_host(lsr_ctx* ctx, const void* src_d, int64_t bytes, void* dst, int64_t chunk_bytes, int n_threads);
+
 /* lsr_recognize_batch (float32 audio) for callers that cannot allocate device memory: code under
  * HIP stream capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
  * in the reference.  Same arguments, same kernels and bit-identical outputs; every intermediate

@@ -79,3 +79,74 @@ def test_streamed_rejects_short_clip_and_overflow_falls_back(decoder):
         eng.recognize_host([np.zeros(100, np.float32)])
     sigs, _ = synthetic.batch(5, 4, 7, start=900)
     assert decoder.recognize_audio(sigs, label_cap=2, streamed=True) == decoder.recognize_audio(sigs, label_cap=32)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int16])
+def test_uploaded_batches_equal_host_concatenation(dtype):
+    """audio_batch / feature_batch send large lists of host arrays through lsr_upload_host (pinned chunks, copy stream):
+    the device buffers hold exactly the host concatenation, for one chunk and for many, with empty arrays in between,
+    and kernels queued right after the call see the data."""
+    from loe_speech_recognition_amd import _native
+
+    eng = _native.get_engine()
+    rng = np.random.default_rng(5)
+    clips = [(rng.standard_normal(int(n)) * 3000).astype(dtype) for n in rng.integers(20000, 60000, size=260)]
+    assert sum(c.nbytes for c in clips) >= eng.UPLOAD_PIPELINE_BYTES
+    ab = eng.audio_batch(clips)
+    assert np.array_equal(ab.audio.cpu().numpy(), np.concatenate(clips))
+    fb = eng.mfcc(ab)                                                   # consumer right behind the upload
+    small = eng.mfcc(eng.audio_batch(clips[:3]))                        # small lists take the single copy
+    assert np.array_equal(fb.feats[:small.total_frames].cpu().numpy(), small.feats.cpu().numpy())
+    # the entry point itself: many small chunks, three threads, zero-length arrays in the list
+    parts = [np.ascontiguousarray(c[:5000]) for c in clips] + [np.zeros(0, dtype)] * 3 + [clips[0]]
+    ptrs = np.array([p.ctypes.data for p in parts], np.uint64)
+    sizes = np.array([p.size for p in parts], np.int64)
+    out = eng.empty((int(sizes.sum()),), eng.torch.int16 if dtype == np.int16 else eng.torch.float32)
+    import ctypes
+    for chunk in (1, 64 << 10, 0):
+        out.zero_()
+        eng._check(eng.lib.lsr_upload_host(eng.ctx, ctypes.c_void_p(ptrs.ctypes.data), ctypes.c_void_p(sizes.ctypes.data),
+                                           len(parts), parts[0].itemsize, chunk, 3, eng._ptr(out)))
+        assert np.array_equal(out.cpu().numpy(), np.concatenate(parts)), chunk
+    assert eng.lib.lsr_upload_host(eng.ctx, None, ctypes.c_void_p(sizes.ctypes.data), 1, 4, 0, 0, eng._ptr(out)) == -1
+
+
+def test_feature_lists_are_uploaded_through_the_pipeline():
+    from loe_speech_recognition_amd import _native
+
+    eng = _native.get_engine()
+    rng = np.random.default_rng(6)
+    feats = [rng.standard_normal((int(t), 39)).astype(np.float32) for t in rng.integers(100, 400, size=600)]
+    assert sum(f.nbytes for f in feats) >= eng.UPLOAD_PIPELINE_BYTES
+    fb = eng.feature_batch(feats)
+    assert fb.feats.shape == (sum(f.shape[0] for f in feats), 39)
+    assert np.array_equal(fb.feats.cpu().numpy(), np.concatenate(feats, axis=0))
+    # a list that does not qualify (a transposed view) still works through the host concatenation
+    odd = [np.asfortranarray(f) for f in feats]
+    assert np.array_equal(eng.feature_batch(odd).feats.cpu().numpy(), np.concatenate(feats, axis=0))
+
+
+def test_download_equals_single_copy():
+    """Engine.to_host / lsr_download_host: a large device tensor comes back bit-identical to tensor.cpu(), for chunk
+    sizes that do and do not divide it; MFCC.batch returns the same arrays as the per-clip calls."""
+    import ctypes
+
+    from loe_speech_recognition_amd import MFCC, _native
+
+    eng = _native.get_engine()
+    t = eng.torch
+    x = t.randn((700001, 39), device=eng.device)                    # 109 MB, not a multiple of any chunk size
+    want = x.cpu().numpy()
+    assert np.array_equal(eng.to_host(x), want)
+    out = np.empty_like(want)
+    for chunk, threads in ((1 << 20, 3), (7 << 20, 16), (1 << 30, 1)):
+        out.fill(0)
+        eng._check(eng.lib.lsr_download_host(eng.ctx, eng._ptr(x), x.numel() * 4, ctypes.c_void_p(out.ctypes.data), chunk,
+                                             threads))
+        assert np.array_equal(out, want), chunk
+    assert eng.lib.lsr_download_host(eng.ctx, eng._ptr(x), -1, ctypes.c_void_p(out.ctypes.data), 0, 0) == -1
+    rng = np.random.default_rng(8)
+    clips = [(rng.standard_normal(int(n)) * 3000).astype(np.float32) for n in rng.integers(20000, 60000, size=400)]
+    feats = MFCC.batch(clips, 16000)                                # upload and download pipelines (24 MB of features)
+    for i in (0, 17, 399):
+        assert np.array_equal(feats[i], MFCC(clips[i], 16000).feature_vector.T)

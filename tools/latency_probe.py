@@ -30,3 +30,6 @@ big16 = [np.round(c).astype(np.int16) for c in big]
 T("recognize_audio(10 000 float32 clips)", lambda: inf.recognize_audio(big), n=5)
 T("recognize_audio(10 000 int16 clips)", lambda: inf.recognize_audio(big16), n=5)
 T("recognize_audio(10 000, streamed=False)", lambda: inf.recognize_audio(big, streamed=False), n=3)
+T("MFCC.batch(10 000 clips) -> host arrays", lambda: MFCC.batch(big, 16000), n=3)
+fl = MFCC.batch(big, 16000)
+T("predict_batch(10 000 host feature arrays)", lambda: inf.predict_batch(fl), n=3)
