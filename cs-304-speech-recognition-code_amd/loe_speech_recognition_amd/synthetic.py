@@ -109,7 +109,7 @@ LOOP_ORDER: List[str] = ["1", "2", "3", "4", "5", "6", "7", "8", "9", "O", "S", 
 
 def load_word_arrays(path: str = MODEL_FILE) -> Dict[str, Tuple[np.ndarray, np.ndarray, np.ndarray]]:
     """{label: (means f32[N,39], covariances f32[N,39,39], transition matrix f32[N,N])} of the
-    models trained on this module's synthetic words (tools/make_synth_models.py)."""
+    models trained on this module's synthetic words (tests/tools/make_synth_models.py)."""
     with np.load(path, allow_pickle=False) as z:
         return {lab: (z[f"{lab}_means"], z[f"{lab}_cov"], z[f"{lab}_trans"]) for lab in WORDS + ["S"]}
 

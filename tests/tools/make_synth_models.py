@@ -7,7 +7,7 @@ turns that into Gaussians and transitions.  Then `--iters` iterations of the ora
 continuous-speech training (forced alignment + re-estimation) refine them.
 Output: a flat npz of float32 means / covariances / transition matrices per label.
 
-    python tools/make_synth_models.py [--clips 300] [--iters 3]
+    python tests/tools/make_synth_models.py [--clips 300] [--iters 3]
 """
 import argparse
 import os
@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cs-304-speech-recognition-code_amd"))
 

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cs-304-speech-recognition-code_amd")]
 from loe_speech_recognition_amd import MFCC, synthetic  # noqa: E402
 from oracle import mfcc_oracle as M  # noqa: E402

@@ -1,14 +1,14 @@
 """One-off large-sample check of the decode stage: every clip of a bench-sized batch is decoded on the device
 (scores, paths, strings) and by the CPU restatement from the same device features; all three must be identical.
 
-    python tools/verify_batch.py [clips] [digits]
+    python tests/tools/verify_batch.py [clips] [digits]
 """
 import multiprocessing as mp
 import os
 import sys
 import time
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, os.path.join(ROOT, "cs-304-speech-recognition-code_amd"))
 sys.path.insert(0, ROOT)
 import numpy as np
