@@ -1,4 +1,4 @@
-/* The multi-GPU step of INTEGRATION.md section C as compilable C: one process per GPU, every rank decodes its
+/* The multi-GPU step through the C ABI: one process per GPU, every rank decodes its
  * contiguous shard and the two exchange steps run through the library's own RCCL entry points.  The caller
  * supplies the broadcast of the 128-byte communicator id (MPI_Bcast, a socket, a shared file ...) and the device
  * buffers.  The Makefile compiles this file against include/lsr_hip.h (object only; it has no main). */
