@@ -98,8 +98,8 @@ __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, co
 #define MP_K1 11             // outputs kept of a 20-point real DFT (k1 = 0..10)
 #define MP_YLD 17            // complex elements per (frame, k1) row: 16 + 1 pad
 #define MP_PLD 164
-#define MP_SLOT_BINS 6
-#define MP_WAVES 4           // wavefronts per workgroup: independent workers that share the stage tables in LDS       // bins per mel slot (61 slots cover the 260 non-zero weights)
+#define MP_SLOT_BINS 6       // bins per mel slot (61 slots cover the 260 non-zero weights)
+#define MP_WAVES 4           // wavefronts per workgroup: independent workers that share the stage tables in LDS
 
 // The load is unconditional (clamped index): a load under a branch is waited for where the branch
 // joins, which would stall the pipeline in the iteration that issues it.
