@@ -152,17 +152,27 @@ extern "C" void lsr_host_dct_matrix(double* out) {
 }
 
 // ---- context ----------------------------------------------------------------------------------
+// Device copy of a host table.  The allocation is kept while the size stays the same (a trainer uploads a
+// model of the same shape every iteration); the copy is ordered after the work already queued on the
+// context's stream, which may still be reading the previous contents.
 template <typename T>
 static int upload(lsr_ctx* ctx, T** dst, const T* src, size_t n, const char* what) {
-    if (*dst) {
+    const size_t bytes = n * sizeof(T);
+    auto it = ctx->table_bytes.find((void*)*dst);
+    if (*dst && (it == ctx->table_bytes.end() || it->second != bytes)) {
         LSR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (it != ctx->table_bytes.end()) ctx->table_bytes.erase(it);
         LSR_HIP_CHECK(ctx, hipFree(*dst));
         *dst = nullptr;
     }
-    hipError_t e = hipMalloc((void**)dst, n * sizeof(T));
-    if (e != hipSuccess)
-        return lsr_fail(ctx, LSR_ERR_HIP, "hipMalloc for %s failed: %s", what, hipGetErrorString(e));
-    LSR_HIP_CHECK(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    if (!*dst) {
+        hipError_t e = hipMalloc((void**)dst, bytes);
+        if (e != hipSuccess)
+            return lsr_fail(ctx, LSR_ERR_HIP, "hipMalloc for %s failed: %s", what, hipGetErrorString(e));
+        ctx->table_bytes[(void*)*dst] = bytes;
+    }
+    LSR_HIP_CHECK(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    LSR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // the source may be a temporary
     return LSR_OK;
 }
 
@@ -264,7 +274,8 @@ extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
     free_ptr(ctx->d_lower_of);
     free_ptr(ctx->d_upper_of);
     lsr_buffer* bufs[] = {&ctx->ws_frame_utt, &ctx->ws_mel, &ctx->ws_uttmax, &ctx->ws_feats,
-                          &ctx->ws_ll, &ctx->ws_tracer, &ctx->ws_slab, &ctx->ws_sep, &ctx->ws_frame_info, &ctx->ws_sort};
+                          &ctx->ws_ll, &ctx->ws_tracer, &ctx->ws_slab, &ctx->ws_sep, &ctx->ws_frame_info, &ctx->ws_sort,
+                          &ctx->ws_mask};
     for (lsr_buffer* b : bufs) free_ptr(b->ptr);
     for (auto& p : ctx->pend) {
         (void)hipEventDestroy(p.start);
@@ -572,7 +583,17 @@ static int decode_chain_any(lsr_ctx* ctx, const char* fn, bool wide, const float
     if (max_frames < 1 || total_chain < n_utts) return lsr_fail(ctx, LSR_ERR_ARG, "%s: bad sizes", fn);
     LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(ctx, total_frames), "emission scores"))) return rc;
-    if ((rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr))) return rc;
+    // chains that hold only part of the model's states (forced alignments) need only those columns
+    const int n_cols = ctx->n_states / ctx->n_mix;
+    bool reachable = ctx->chain_emission_mode == LSR_CHAIN_EMISSION_REACHABLE ||
+                     (ctx->chain_emission_mode == LSR_CHAIN_EMISSION_AUTO && 4 * total_chain < 3 * (int64_t)n_utts * n_cols);
+    if (ctx->n_mix > 1) reachable = false;
+    if (reachable)
+        rc = lsr_launch_emission_chains(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr, frame_off_d, n_utts, chain_off_d,
+                                        chain_state_d);
+    else
+        rc = lsr_launch_emission(ctx, feats_d, total_frames, (float*)ctx->ws_ll.ptr);
+    if (rc) return rc;
     return lsr_launch_viterbi_chain(ctx, (const float*)ctx->ws_ll.ptr, frame_off_d, n_utts, total_frames, max_frames,
                                     chain_off_d, total_chain, chain_state_d, chain_band_d, chain_start_d, scores_d,
                                     paths_d, final_d, wide);
@@ -594,6 +615,14 @@ extern "C" int lsr_decode_chain_batch_wide(lsr_ctx* ctx, const float* feats_d, c
     return decode_chain_any(ctx, "lsr_decode_chain_batch_wide", true, feats_d, frame_off_d, n_utts, total_frames,
                             max_frames, chain_off_d, total_chain, chain_state_d, chain_band_d, chain_start_d, scores_d,
                             paths_d, nullptr);
+}
+
+extern "C" int lsr_chain_emission_mode(lsr_ctx* ctx, int mode) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (mode != LSR_CHAIN_EMISSION_AUTO && mode != LSR_CHAIN_EMISSION_ALL && mode != LSR_CHAIN_EMISSION_REACHABLE)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_chain_emission_mode: unknown mode %d", mode);
+    ctx->chain_emission_mode = mode;
+    return LSR_OK;
 }
 
 extern "C" int lsr_accumulate_stats(lsr_ctx* ctx, const float* feats_d, const int32_t* slot_d, int64_t total_frames,

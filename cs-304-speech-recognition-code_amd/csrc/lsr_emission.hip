@@ -53,6 +53,101 @@ __device__ __forceinline__ void em_swap16(double& a, double& b) {
     b = __hiloint2double(hi[1], lo[1]);
 }
 
+// Ring of A operands in flight per wavefront (places of the operand stream, see below): divides the places of a
+// state and is even.
+template <bool TRI>
+struct em_ring {
+    static constexpr int SLOTS = TRI ? LSR_TRI_SLOTS : LSR_JBLOCKS * LSR_KSTEPS;
+    static constexpr int RING = TRI ? 14 : 10;
+};
+
+// Squared whitened components of the wavefront's 64 frames for ONE Gaussian, summed per lane into ss[4] (lane
+// group g = rows 4 jb + g of every row block, frame column q): the MFMA loop.
+//
+// A values are a stream: the blocks of a Gaussian in the order of their use, SLOTS places per Gaussian.  RING of
+// them are in flight: the register of a block is refilled with the block RING places further down the stream as
+// soon as its four MFMAs are issued, which is ~900 cycles before that block is needed.  `cur` is the stream of
+// this Gaussian (lane's element of place 0), `nxt` that of the Gaussian scored next: with SPLIT = false the
+// Gaussians are consecutive in memory and the stream simply runs on (nxt is unused).
+template <bool TRI, bool SPLIT>
+__device__ __forceinline__ void em_gaussian(v2d (&w)[em_ring<TRI>::RING / 2], const double (&x)[4][LSR_KSTEPS],
+                                            const v2d* __restrict__ cur, const v2d* __restrict__ nxt, double (&ss)[4]) {
+    constexpr int SLOTS = em_ring<TRI>::SLOTS, RING = em_ring<TRI>::RING;
+    // place v (odd: both places of its register pair are used) has been consumed: fetch the pair RING places on
+    auto refill = [&](int v) {
+        const int pn = v / 2 + RING / 2;                     // register pair = two consecutive places
+        if (!SPLIT || pn < SLOTS / 2) w[(v % RING) / 2] = cur[pn * 16];
+        else w[(v % RING) / 2] = nxt[(pn - SLOTS / 2) * 16];
+    };
+    ss[0] = ss[1] = ss[2] = ss[3] = 0.0;
+    // Row blocks are taken two at a time (jb, jb + 1) with their feature blocks interleaved: eight
+    // independent accumulator chains keep the matrix pipe fed (a chain can take a new MFMA only
+    // when its previous one has finished).  Place in the stream: pair base + 2 t (+ 1 for the second).
+#pragma unroll
+    for (int jp = 0; jp < LSR_JBLOCKS; jp += 2) {
+        const int ka = TRI ? jp : 0, kb0 = TRI ? jp + 1 : 0;             // first feature block of each row block
+        const int na = LSR_KSTEPS - ka, nb = LSR_KSTEPS - kb0;
+        // blocks before row block jp: sum_{j < jp} (10 - j) for a triangular matrix
+        const int v_base = TRI ? jp * LSR_KSTEPS - jp * (jp - 1) / 2 : jp * LSR_KSTEPS;
+        double acc[8];
+#pragma unroll
+        for (int t = 0; t < LSR_KSTEPS; ++t) {
+            if (t < na) {
+                const int v = v_base + 2 * t;
+                const double wv = w[(v % RING) / 2][v % 2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][ka + t], t == 0 ? 0.0 : acc[q], 0, 0, 0);
+                if (v % 2 == 1) refill(v);
+            }
+            if (t < nb) {
+                const int v = v_base + 2 * t + 1;
+                const double wv = w[(v % RING) / 2][v % 2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[4 + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb0 + t], t == 0 ? 0.0 : acc[4 + q], 0, 0, 0);
+                if (v % 2 == 1) refill(v);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ss[q] = fma(acc[q], acc[q], ss[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ss[q] = fma(acc[4 + q], acc[4 + q], ss[q]);
+    }
+    // the padding places of the stream carry no block, but their turn to refill a register remains
+#pragma unroll
+    for (int v = TRI ? 55 : SLOTS; v < SLOTS; ++v)
+        if (v % 2 == 1) refill(v);
+}
+
+// log density of the Gaussian for the frame of each lane from the per-lane sums of em_gaussian: folds the four
+// lane groups (rows of the C tiles) so that lane l ends up with frame l of the tile
+__device__ __forceinline__ double em_fold(double (&ss)[4], double log_norm) {
+    em_swap32(ss[0], ss[2]);
+    em_swap32(ss[1], ss[3]);
+    double v0 = ss[0] + ss[2];            // lanes 0..31: frame tile 0, lanes 32..63: frame tile 2
+    double v1 = ss[1] + ss[3];            // frame tiles 1 and 3
+    em_swap16(v0, v1);
+    const double maha = v0 + v1;
+    return -0.5 * (log_norm + maha);
+}
+
+// B-operand source of a tile: x~[frame 16q + col][k = 4ks + grp]; frames beyond the batch are zero
+__device__ __forceinline__ void em_load_frames(double (&x)[4][LSR_KSTEPS], const float* __restrict__ feats, int64_t f0,
+                                               int64_t total_frames, int col, int grp) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t f = f0 + 16 * q + col;
+        const bool live = f < total_frames;
+        const float* row = feats + (live ? f : 0) * LSR_DIM;
+#pragma unroll
+        for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
+            const int k = 4 * ks + grp;
+            x[q][ks] = k < LSR_DIM ? (live ? (double)row[k] : 0.0) : 1.0;      // feature 39 is the constant
+        }
+    }
+}
+
 template <bool TRI, bool MIX>
 __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
@@ -82,28 +177,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
         const int64_t f0 = t * 64;
         p += c1 - c0;
 
-        // B-operand source: x~[frame 16q + col][k = 4ks + grp]; frames beyond the batch are zero
         if (t != loaded) {
             loaded = t;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t f = f0 + 16 * q + col;
-                const bool live = f < total_frames;
-                const float* row = feats + (live ? f : 0) * LSR_DIM;
-#pragma unroll
-                for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
-                    const int k = 4 * ks + grp;
-                    x[q][ks] = k < LSR_DIM ? (live ? (double)row[k] : 0.0) : 1.0;      // feature 39 is the constant
-                }
-            }
+            em_load_frames(x, feats, f0, total_frames, col, grp);
         }
 
-        // A values are a stream: the blocks of a state in the order of their use (see the loop below),
-        // SLOTS places per state, states back to back.  RING of them are in flight: the register of a
-        // block is refilled with the block RING places further down the stream as soon as its four
-        // MFMAs are issued, which is ~900 cycles before that block is needed.
-        constexpr int SLOTS = TRI ? LSR_TRI_SLOTS : LSR_JBLOCKS * LSR_KSTEPS;
-        constexpr int RING = TRI ? 14 : 10;                                    // divides SLOTS, even
+        constexpr int SLOTS = em_ring<TRI>::SLOTS, RING = em_ring<TRI>::RING;
         const int s_begin = c0 * n_mix, s_end = c1 * n_mix;
         const int a_idx = (lane >> 4) * 4 + (lane & 3);
         // two consecutive places of the stream are interleaved in memory: one 16-byte load fills two registers
@@ -117,55 +196,10 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
         double run = 0.0;          // log-sum of the components of the current state seen so far
         int mix = 0;
         for (int s = s_begin; s < s_end; ++s) {
-            const v2d* ahead = (const v2d*)wfrag + ((size_t)s * SLOTS + RING) * 8 + a_idx;      // wave-uniform base
-            double ss[4] = {0.0, 0.0, 0.0, 0.0};
-            // Row blocks are taken two at a time (jb, jb + 1) with their feature blocks interleaved: eight
-            // independent accumulator chains keep the matrix pipe fed (a chain can take a new MFMA only
-            // when its previous one has finished).  Place in the stream: pair base + 2 t (+ 1 for the second).
-#pragma unroll
-            for (int jp = 0; jp < LSR_JBLOCKS; jp += 2) {
-                const int ka = TRI ? jp : 0, kb0 = TRI ? jp + 1 : 0;             // first feature block of each row block
-                const int na = LSR_KSTEPS - ka, nb = LSR_KSTEPS - kb0;
-                // blocks before row block jp: sum_{j < jp} (10 - j) for a triangular matrix
-                const int v_base = TRI ? jp * LSR_KSTEPS - jp * (jp - 1) / 2 : jp * LSR_KSTEPS;
-                double acc[8];
-#pragma unroll
-                for (int t = 0; t < LSR_KSTEPS; ++t) {
-                    if (t < na) {
-                        const int v = v_base + 2 * t;
-                        const double wv = w[(v % RING) / 2][v % 2];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][ka + t], t == 0 ? 0.0 : acc[q], 0, 0, 0);
-                        if (v % 2 == 1) w[(v % RING) / 2] = ahead[(v / 2) * 16];      // both places of the pair are used
-                    }
-                    if (t < nb) {
-                        const int v = v_base + 2 * t + 1;
-                        const double wv = w[(v % RING) / 2][v % 2];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[4 + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, x[q][kb0 + t], t == 0 ? 0.0 : acc[4 + q], 0, 0, 0);
-                        if (v % 2 == 1) w[(v % RING) / 2] = ahead[(v / 2) * 16];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ss[q] = fma(acc[q], acc[q], ss[q]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ss[q] = fma(acc[4 + q], acc[4 + q], ss[q]);
-            }
-            // the padding places of the stream carry no block, but their turn to refill a register remains
-#pragma unroll
-            for (int v = TRI ? 55 : SLOTS; v < SLOTS; ++v)
-                if (v % 2 == 1) w[(v % RING) / 2] = ahead[(v / 2) * 16];
-            const double ln = lognorm[s];
-            // fold the four lane groups (rows of the C tiles) so that group g keeps frame tile g
-            em_swap32(ss[0], ss[2]);
-            em_swap32(ss[1], ss[3]);
-            double v0 = ss[0] + ss[2];            // lanes 0..31: frame tile 0, lanes 32..63: frame tile 2
-            double v1 = ss[1] + ss[3];            // frame tiles 1 and 3
-            em_swap16(v0, v1);
-            const double maha = v0 + v1;
-            const double lp = -0.5 * (ln + maha);
+            const v2d* cur = (const v2d*)wfrag + (size_t)s * (SLOTS * 8) + a_idx;      // wave-uniform base
+            double ss[4];
+            em_gaussian<TRI, false>(w, x, cur, cur, ss);
+            const double lp = em_fold(ss, lognorm[s]);
             if (!MIX) {
                 tile[wave][lane][((s - s_begin) ^ lane) & (EM_RUN - 1)] = (float)lp;
             } else {
@@ -206,6 +240,188 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
     }
 }
 
+// ---- scores of selected states only ------------------------------------------------------------------------
+// Forced alignment reads, for the frames of an utterance, only the columns of the states in that utterance's
+// chain (hidden_markov_model.py:638-664: the chain S d S d ... S holds the models of the utterance's own words).
+// tile_mask[t] (two 64-bit words) holds the states any utterance overlapping frames 64 t .. 64 t + 63 can
+// visit, pair_off the running count of set bits.  The work list is the (tile, selected state) pairs in tile
+// order, cut into equal contiguous shares like the full kernel's; columns outside the mask are left as they are.
+// a wave-uniform 64-bit value moved to scalar registers
+__device__ __forceinline__ unsigned long long em_uniform(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool TRI>
+__global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
+    const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
+    const double* __restrict__ lognorm, float* __restrict__ ll, int ll_stride,
+    const unsigned long long* __restrict__ tile_mask, const int64_t* __restrict__ pair_off) {
+    __shared__ float tile[EM_WAVES][64][EM_RUN];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int64_t n_tiles = (total_frames + 63) / 64;
+    const int64_t n_pairs = (int64_t)em_uniform((unsigned long long)pair_off[n_tiles]);
+    const int64_t n_waves = (int64_t)gridDim.x * EM_WAVES, me = (int64_t)blockIdx.x * EM_WAVES + wave;
+    int64_t p = (int64_t)em_uniform((unsigned long long)(me * n_pairs / n_waves));
+    const int64_t p_end = (int64_t)em_uniform((unsigned long long)((me + 1) * n_pairs / n_waves));
+    if (p >= p_end) return;
+
+    // the tile that holds pair p: the last one whose running count is <= p
+    int64_t t = 0;
+    {
+        int64_t hi = n_tiles;
+        while (hi - t > 1) {
+            const int64_t mid = (t + hi) >> 1;
+            if ((int64_t)em_uniform((unsigned long long)pair_off[mid]) <= p) t = mid; else hi = mid;
+        }
+    }
+    // states of tile t not yet scored
+    unsigned long long m0 = em_uniform(tile_mask[2 * t]), m1 = em_uniform(tile_mask[2 * t + 1]);
+    for (int64_t skip = p - (int64_t)em_uniform((unsigned long long)pair_off[t]); skip > 0; --skip) {
+        if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+    }
+
+    int64_t loaded = -1;
+    double x[4][LSR_KSTEPS];
+    while (p < p_end) {
+        if ((m0 | m1) == 0) {                 // tile finished (p < p_end <= n_pairs: a later tile has states left)
+            ++t;
+            m0 = em_uniform(tile_mask[2 * t]);
+            m1 = em_uniform(tile_mask[2 * t + 1]);
+            continue;
+        }
+        int cnt = __popcll(m0) + __popcll(m1);
+        if (cnt > EM_RUN) cnt = EM_RUN;
+        if ((int64_t)cnt > p_end - p) cnt = (int)(p_end - p);
+        p += cnt;
+        const int64_t f0 = t * 64;
+        if (t != loaded) {
+            loaded = t;
+            em_load_frames(x, feats, f0, total_frames, col, grp);
+        }
+
+        constexpr int SLOTS = em_ring<TRI>::SLOTS, RING = em_ring<TRI>::RING;
+        const int a_idx = (lane >> 4) * 4 + (lane & 3);
+        auto pop = [&]() -> int {
+            int s;
+            if (m0) {
+                s = __builtin_ctzll(m0);
+                m0 &= m0 - 1;
+            } else {
+                s = 64 + __builtin_ctzll(m1);
+                m1 &= m1 - 1;
+            }
+            return s;
+        };
+        int s = pop();
+        v2d w[RING / 2];
+        {
+            const v2d* src = (const v2d*)wfrag + (size_t)s * (SLOTS * 8) + a_idx;
+#pragma unroll
+            for (int v = 0; v < RING / 2; ++v) w[v] = src[v * 16];
+        }
+        int my_col = 0;                                        // column this lane writes out: the lane-th state of the run
+#pragma nounroll
+        for (int i = 0; i < cnt; ++i) {
+            const int s_next = i + 1 < cnt ? pop() : s;        // after the last state the ring refills with places it never uses
+            const v2d* cur = (const v2d*)wfrag + (size_t)s * (SLOTS * 8) + a_idx;
+            const v2d* nxt = (const v2d*)wfrag + (size_t)s_next * (SLOTS * 8) + a_idx;
+            double ss[4];
+            em_gaussian<TRI, true>(w, x, cur, nxt, ss);
+            const double lp = em_fold(ss, lognorm[s]);
+            tile[wave][lane][(i ^ lane) & (EM_RUN - 1)] = (float)lp;
+            if (lane == i) my_col = s;
+            s = s_next;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < cnt) {
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r)
+                ll[(f0 + r) * ll_stride + my_col] = tile[wave][r][(lane ^ r) & (EM_RUN - 1)];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// states visited by the chain of each utterance: one wavefront per utterance
+__global__ __launch_bounds__(64) void lsr_chain_utt_mask_kernel(const int64_t* __restrict__ chain_off,
+                                                                const int32_t* __restrict__ chain_state, int n_cols,
+                                                                unsigned long long* __restrict__ utt_mask) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t c0 = chain_off[b], c1 = chain_off[b + 1];
+    unsigned long long m0 = 0, m1 = 0;
+    for (int64_t i = c0 + lane; i < c1; i += 64) {
+        const int s = chain_state[i];
+        if (s >= 0 && s < n_cols) {
+            if (s < 64) m0 |= 1ull << s; else m1 |= 1ull << (s - 64);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m0 |= __shfl_xor(m0, o);
+        m1 |= __shfl_xor(m1, o);
+    }
+    if (lane == 0) {
+        utt_mask[2 * b] = m0;
+        utt_mask[2 * b + 1] = m1;
+    }
+}
+
+// union of the utterance masks over the utterances that own frames of each 64-frame tile: one thread per tile
+__global__ __launch_bounds__(256) void lsr_chain_tile_mask_kernel(const int64_t* __restrict__ frame_off, int n_utts,
+                                                                  int64_t total_frames,
+                                                                  const unsigned long long* __restrict__ utt_mask,
+                                                                  unsigned long long* __restrict__ tile_mask,
+                                                                  int32_t* __restrict__ tile_count) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_tiles = (total_frames + 63) / 64;
+    if (t >= n_tiles) return;
+    const int64_t f0 = t * 64, f1 = f0 + 64 < total_frames ? f0 + 64 : total_frames;
+    int lo = 0, hi = n_utts;                          // last utterance that starts at or before f0
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] <= f0) lo = mid; else hi = mid;
+    }
+    unsigned long long m0 = 0, m1 = 0;
+    for (int b = lo; b < n_utts && frame_off[b] < f1; ++b) {
+        m0 |= utt_mask[2 * b];
+        m1 |= utt_mask[2 * b + 1];
+    }
+    tile_mask[2 * t] = m0;
+    tile_mask[2 * t + 1] = m1;
+    tile_count[t] = __popcll(m0) + __popcll(m1);
+}
+
+// exclusive running sum of the tile counts (one workgroup: every thread a contiguous piece, the pieces' totals
+// scanned in LDS); out has n + 1 entries
+__global__ __launch_bounds__(1024) void lsr_chain_scan_kernel(const int32_t* __restrict__ count, int64_t n,
+                                                              int64_t* __restrict__ out) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t a = tid * per < n ? tid * per : n, b = a + per < n ? a + per : n;
+    int64_t sum = 0;
+    for (int64_t i = a; i < b; ++i) sum += count[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = tid ? part[tid - 1] : 0;
+    for (int64_t i = a; i < b; ++i) {
+        out[i] = run;
+        run += count[i];
+    }
+    if (tid == 1023) out[n] = part[1023];
+}
+
 int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d) {
     // persistent grid: as many workgroups as fit a compute unit (three of 32 KiB of LDS and <= 168 VGPRs;
     // two for mixtures), fewer when the batch has fewer (tile, state) pairs than that many wavefronts
@@ -222,5 +438,37 @@ int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames
                        ctx->d_wfrag, ctx->d_lognorm, ctx->d_logw, ctx->n_states, ctx->n_mix, ll_d, lsr_ctx_ll_stride(ctx));
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_emission_kernel");
+    return LSR_OK;
+}
+
+int lsr_launch_emission_chains(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d,
+                               const int64_t* frame_off_d, int n_utts, const int64_t* chain_off_d,
+                               const int32_t* chain_state_d) {
+    if (ctx->n_mix > 1) return lsr_launch_emission(ctx, feats_d, total_frames, ll_d);      // mixtures: all states
+    const int n_cols = ctx->n_states;
+    const int64_t n_tiles = (total_frames + 63) / 64;
+    // [utterance masks 16 B][tile masks 16 B][running counts 8 B x (tiles + 1)][tile counts 4 B]
+    const size_t need = (size_t)n_utts * 16 + (size_t)n_tiles * 16 + (size_t)(n_tiles + 1) * 8 + (size_t)n_tiles * 4;
+    int rc = lsr_reserve(ctx, &ctx->ws_mask, need, "state masks of the alignment chains");
+    if (rc) return rc;
+    unsigned long long* utt_mask = (unsigned long long*)ctx->ws_mask.ptr;
+    unsigned long long* tile_mask = utt_mask + (size_t)n_utts * 2;
+    int64_t* pair_off = (int64_t*)(tile_mask + (size_t)n_tiles * 2);
+    int32_t* tile_count = (int32_t*)(pair_off + n_tiles + 1);
+    lsr_prof_begin(ctx, LSR_K_EMISSION);
+    hipLaunchKernelGGL(lsr_chain_utt_mask_kernel, dim3((unsigned)n_utts), dim3(64), 0, ctx->stream, chain_off_d,
+                       chain_state_d, n_cols, utt_mask);
+    hipLaunchKernelGGL(lsr_chain_tile_mask_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream,
+                       frame_off_d, n_utts, total_frames, utt_mask, tile_mask, tile_count);
+    hipLaunchKernelGGL(lsr_chain_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_count, n_tiles, pair_off);
+    // the number of pairs is only known on the device: the full persistent grid, surplus wavefronts leave at once
+    int64_t blocks = (n_tiles * n_cols + EM_WAVES - 1) / EM_WAVES;
+    if (blocks > 3 * (int64_t)ctx->n_cus) blocks = 3 * (int64_t)ctx->n_cus;
+    void (*kern)(const float*, int64_t, const double*, const double*, float*, int, const unsigned long long*, const int64_t*) =
+        ctx->whiten_triangular ? lsr_emission_masked_kernel<true> : lsr_emission_masked_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream, feats_d, total_frames,
+                       ctx->d_wfrag, ctx->d_lognorm, ll_d, lsr_ctx_ll_stride(ctx), tile_mask, pair_off);
+    lsr_prof_end(ctx);
+    LSR_LAUNCH_CHECK(ctx, "lsr_emission_masked_kernel");
     return LSR_OK;
 }

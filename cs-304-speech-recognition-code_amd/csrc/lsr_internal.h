@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "lsr_hip.h"
@@ -26,6 +27,8 @@ struct lsr_ctx {
     hipStream_t stream = nullptr;
     std::string error;
 
+    std::unordered_map<void*, size_t> table_bytes;   // size of every table allocated by upload()
+
     // front-end tables (device)
     double* d_window = nullptr;      // [320]
     double* d_tw_stage = nullptr;    // [11][16][2]  W320^(n2 k1): twiddles between the two FFT stages
@@ -42,6 +45,8 @@ struct lsr_ctx {
     int n_mix = 1;                   // components per state (n_states counts components)
     double* d_logw = nullptr;        // [S] log mixture weights (n_mix > 1 only)
 
+    int chain_emission_mode = 0;     // LSR_CHAIN_EMISSION_*
+
     // loop graph (device)
     int g_states = 0, g_words = 0, g_silence = -1;
     float* d_band = nullptr;         // [3][128]
@@ -53,7 +58,7 @@ struct lsr_ctx {
     int between_is_f64 = 1;
 
     // workspace
-    lsr_buffer ws_frame_utt, ws_mel, ws_uttmax, ws_feats, ws_ll, ws_tracer, ws_slab, ws_sep, ws_frame_info, ws_sort;
+    lsr_buffer ws_frame_utt, ws_mel, ws_uttmax, ws_feats, ws_ll, ws_tracer, ws_slab, ws_sep, ws_frame_info, ws_sort, ws_mask;
 
     // host -> device pipeline of lsr_recognize_host (created on first use)
     struct lsr_pipeline* pipeline = nullptr;
@@ -143,6 +148,11 @@ static inline int lsr_ctx_ll_stride(const lsr_ctx* ctx) {
     return ctx->n_states / (ctx->n_mix > 0 ? ctx->n_mix : 1) > 64 ? 128 : 64;
 }
 int lsr_launch_emission(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d);
+// emission scores of the states the alignment chains can visit only (per 64-frame tile); other columns keep
+// whatever they held
+int lsr_launch_emission_chains(lsr_ctx* ctx, const float* feats_d, int64_t total_frames, float* ll_d,
+                               const int64_t* frame_off_d, int n_utts, const int64_t* chain_off_d,
+                               const int32_t* chain_state_d);
 int lsr_launch_viterbi_loop(lsr_ctx* ctx, const float* ll_d, const int64_t* frame_off_d, int n_utts,
                             int64_t total_frames, int max_frames, float* scores_d, int8_t* paths_d,
                             uint8_t* labels_d, int32_t* n_labels_d, int label_cap, int8_t* tracer_d = nullptr);

@@ -1,11 +1,19 @@
-/* _lsr_pyhelper: the data pointers and lengths of a Python list of 1-D NumPy arrays in one pass
- * (arr.ctypes.data costs about 2 us per array in Python; a batch has 10 000 clips).  Host-side
- * glue of the Python binding only: liblsr_hip.so itself has no Python dependency. */
+/* _lsr_pyhelper: host-side glue of the Python binding (liblsr_hip.so itself has no Python dependency).
+ *   - the data pointers and lengths of a Python list of NumPy arrays in one pass (arr.ctypes.data
+ *     costs about 2 us per array in Python; a batch has 10 000 clips);
+ *   - the factorisation of a batch of covariance matrices on a pool of threads, calling the LAPACK
+ *     routines SciPy and NumPy call (through the function pointers SciPy exports) so that the results
+ *     carry the same bits as scipy.linalg.eigh / numpy.linalg.qr, which hold the GIL or run one
+ *     matrix after the other. */
 #define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <numpy/arrayobject.h>
+#include <math.h>
+#include <pthread.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 /* clip_table(seq, ptrs, lens) -> int
  * seq: sequence of arrays; ptrs: writable uint64[n] buffer; lens: writable int64[n] buffer.
@@ -96,7 +104,190 @@ static PyObject* array_table(PyObject* self, PyObject* args) {
     return PyLong_FromLong(result);
 }
 
+/* ---- batched covariance factorisation ------------------------------------------------------------------
+ * For every selected matrix C (symmetric, row-major, only the lower triangle is read, as
+ * scipy.linalg.eigh(C, lower=True) does):
+ *   lam, V   = dsyevr('V', 'A', 'L') with the workspace sizes of its own query  (scipy.linalg.eigh, driver "evr")
+ *   U[k][j]  = V[k][j] * sqrt(1 / lam[j])                                       (the whitening matrix SciPy's frozen
+ *                                                                                multivariate_normal keeps)
+ *   L        = R^T of U^T = Q R (dgeqrf on U^T, upper triangle kept)            (numpy.linalg.qr(U.T, mode="r").T)
+ * status = LAPACK's info of dsyevr (or -1000 when it found fewer than n eigenvalues, -2000 - info for dgeqrf).
+ * Matrices first, first + step, ... are processed; the rows of the others are left untouched. */
+typedef void (*dsyevr_fn)(char*, char*, char*, int*, double*, int*, double*, double*, int*, int*, double*, int*, double*,
+                          double*, int*, int*, double*, int*, int*, int*, int*);
+typedef void (*dgeqrf_fn)(int*, int*, double*, int*, double*, double*, int*, int*);
+
+struct factor_job {
+    dsyevr_fn syevr;
+    dgeqrf_fn geqrf;
+    const double* cov;
+    double *lam, *whiten, *tri;
+    int32_t* status;
+    int n, n_mats, first, step, tid, n_threads;
+    int lwork, liwork, qwork;
+    int failed;          /* allocation failure */
+};
+
+static void* factor_worker(void* arg) {
+    struct factor_job* J = (struct factor_job*)arg;
+    const int n = J->n;
+    const size_t nn = (size_t)n * n;
+    double* a = (double*)malloc(sizeof(double) * (2 * nn + (size_t)J->lwork + (size_t)J->qwork + 2 * (size_t)n));
+    int* iw = (int*)malloc(sizeof(int) * ((size_t)J->liwork + 2 * (size_t)n));
+    if (!a || !iw) {
+        free(a);
+        free(iw);
+        J->failed = 1;
+        return NULL;
+    }
+    double *z = a + nn, *work = z + nn, *qw = work + J->lwork, *w = qw + J->qwork, *tau = w + n;
+    int *iwork = iw, *isuppz = iw + J->liwork;
+    for (int i = J->first + J->step * J->tid; i < J->n_mats; i += J->step * J->n_threads) {
+        const double* c = J->cov + (size_t)i * nn;
+        /* column-major copy of the row-major matrix: a[r + col * n] = C[r][col] */
+        for (int r = 0; r < n; ++r)
+            for (int col = 0; col < n; ++col) a[r + (size_t)col * n] = c[(size_t)r * n + col];
+        char jobz = 'V', range = 'A', uplo = 'L';
+        int nn_ = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = J->lwork, liwork = J->liwork;
+        double vl = 0.0, vu = 1.0, abstol = 0.0;
+        J->syevr(&jobz, &range, &uplo, &nn_, a, &lda, &vl, &vu, &il, &iu, &abstol, &m, w, z, &ldz, isuppz, work, &lwork,
+                 iwork, &liwork, &info);
+        if (info == 0 && m != n) info = -1000;
+        double* U = J->whiten + (size_t)i * nn;
+        double* L = J->tri + (size_t)i * nn;
+        for (int j = 0; j < n; ++j) {
+            J->lam[(size_t)i * n + j] = w[j];
+            const double scale = sqrt(1.0 / w[j]);
+            for (int k = 0; k < n; ++k) U[(size_t)k * n + j] = z[k + (size_t)j * n] * scale;
+        }
+        if (info == 0) {
+            /* the row-major U read as column-major is U^T: factor it in place of a copy */
+            memcpy(L, U, sizeof(double) * nn);
+            int qinfo = 0, qwork = J->qwork;
+            J->geqrf(&nn_, &nn_, L, &lda, tau, qw, &qwork, &qinfo);
+            if (qinfo != 0) info = -2000 - qinfo;
+            /* R[j][k] (j <= k) sits at L[j + k * n] = row-major L[k][j]: zero what lies above the diagonal of L */
+            for (int k = 0; k < n; ++k)
+                for (int j = k + 1; j < n; ++j) L[(size_t)k * n + j] = 0.0;
+        } else {
+            memset(L, 0, sizeof(double) * nn);
+        }
+        J->status[i] = info;
+    }
+    free(a);
+    free(iw);
+    return NULL;
+}
+
+static void* capsule_pointer(PyObject* cap) {
+    if (!PyCapsule_CheckExact(cap)) {
+        PyErr_SetString(PyExc_TypeError, "factor_batch: expected the PyCapsule of a LAPACK routine");
+        return NULL;
+    }
+    return PyCapsule_GetPointer(cap, PyCapsule_GetName(cap));
+}
+
+/* factor_batch(dsyevr, dgeqrf, cov, lam, whiten, tri, status, n_mats, n, first, step, threads) -> None */
+static PyObject* factor_batch(PyObject* self, PyObject* args) {
+    PyObject *cap_syevr, *cap_geqrf;
+    Py_buffer cov, lam, whiten, tri, status;
+    int n_mats, n, first, step, threads;
+    if (!PyArg_ParseTuple(args, "OOy*w*w*w*w*iiiii", &cap_syevr, &cap_geqrf, &cov, &lam, &whiten, &tri, &status, &n_mats, &n,
+                          &first, &step, &threads))
+        return NULL;
+    PyObject* result = NULL;
+    struct factor_job* jobs = NULL;
+    pthread_t* tids = NULL;
+    dsyevr_fn syevr = (dsyevr_fn)capsule_pointer(cap_syevr);
+    dgeqrf_fn geqrf = syevr ? (dgeqrf_fn)capsule_pointer(cap_geqrf) : NULL;
+    if (!syevr || !geqrf) goto done;
+    const Py_ssize_t nn = (Py_ssize_t)n * n;
+    if (n < 1 || n_mats < 0 || first < 0 || step < 1 || cov.len < (Py_ssize_t)(n_mats * nn * sizeof(double)) ||
+        whiten.len < cov.len || tri.len < cov.len || lam.len < (Py_ssize_t)(n_mats * (Py_ssize_t)n * sizeof(double)) ||
+        status.len < (Py_ssize_t)(n_mats * sizeof(int32_t))) {
+        PyErr_SetString(PyExc_ValueError, "factor_batch: buffer sizes do not match n_mats x n x n");
+        goto done;
+    }
+    {
+        /* workspace queries, as scipy.linalg.eigh (dsyevr_lwork) and numpy.linalg.qr (lwork = -1) make them */
+        char jobz = 'V', range = 'A', uplo = 'L';
+        int nn_ = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = -1, liwork = -1, iwq = 0, isup = 0;
+        double vl = 0.0, vu = 1.0, abstol = 0.0, wq = 0.0, dummy = 0.0;
+        syevr(&jobz, &range, &uplo, &nn_, &dummy, &lda, &vl, &vu, &il, &iu, &abstol, &m, &dummy, &dummy, &ldz, &isup, &wq,
+              &lwork, &iwq, &liwork, &info);
+        if (info != 0) {
+            PyErr_Format(PyExc_RuntimeError, "factor_batch: dsyevr workspace query failed (info %d)", info);
+            goto done;
+        }
+        int q_lwork = -1, qinfo = 0;
+        double qq = 0.0;
+        geqrf(&nn_, &nn_, &dummy, &lda, &dummy, &qq, &q_lwork, &qinfo);
+        if (qinfo != 0) {
+            PyErr_Format(PyExc_RuntimeError, "factor_batch: dgeqrf workspace query failed (info %d)", qinfo);
+            goto done;
+        }
+        int count = (n_mats - first + step - 1) / step;
+        if (count < 0) count = 0;
+        if (threads < 1) threads = 1;
+        if (threads > count) threads = count > 0 ? count : 1;
+        jobs = (struct factor_job*)calloc((size_t)threads, sizeof(struct factor_job));
+        tids = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+        if (!jobs || !tids) {
+            PyErr_NoMemory();
+            goto done;
+        }
+        for (int t = 0; t < threads; ++t) {
+            struct factor_job* J = &jobs[t];
+            J->syevr = syevr;
+            J->geqrf = geqrf;
+            J->cov = (const double*)cov.buf;
+            J->lam = (double*)lam.buf;
+            J->whiten = (double*)whiten.buf;
+            J->tri = (double*)tri.buf;
+            J->status = (int32_t*)status.buf;
+            J->n = n;
+            J->n_mats = n_mats;
+            J->first = first;
+            J->step = step;
+            J->tid = t;
+            J->n_threads = threads;
+            J->lwork = (int)wq > 1 ? (int)wq : 1;
+            J->liwork = iwq > 1 ? iwq : 1;
+            J->qwork = (int)qq > n ? (int)qq : n;
+        }
+        int failed = 0;
+        Py_BEGIN_ALLOW_THREADS
+        int started = 0;
+        for (int t = 1; t < threads; ++t) {
+            if (pthread_create(&tids[t], NULL, factor_worker, &jobs[t]) != 0) break;
+            ++started;
+        }
+        factor_worker(&jobs[0]);
+        for (int t = 1; t <= started; ++t) pthread_join(tids[t], NULL);
+        /* shares whose thread could not be started run here */
+        for (int t = started + 1; t < threads; ++t) factor_worker(&jobs[t]);
+        for (int t = 0; t < threads; ++t) failed |= jobs[t].failed;
+        Py_END_ALLOW_THREADS
+        if (failed) {
+            PyErr_NoMemory();
+            goto done;
+        }
+    }
+    result = Py_None;
+    Py_INCREF(result);
+done:
+    free(jobs);
+    free(tids);
+    PyBuffer_Release(&cov);
+    PyBuffer_Release(&lam);
+    PyBuffer_Release(&whiten);
+    PyBuffer_Release(&tri);
+    PyBuffer_Release(&status);
+    return result;
+}
+
 static PyMethodDef methods[] = {
+    {"factor_batch", factor_batch, METH_VARARGS, "eigendecomposition, whitening and triangular factor of a batch of covariances"},
     {"array_table", array_table, METH_VARARGS, "fill pointer and size tables of a list of n-D int16/float32 arrays"},
     {"clip_table", clip_table, METH_VARARGS, "fill pointer and length tables of a list of 1-D int16/float32 arrays"},
     {NULL, NULL, 0, NULL}};

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64) void lsr_viterbi_kernel(vit_args A) {
         n = (int)(A.chain_off[b + 1] - c0);
         const bool live = lane < n;
         const int64_t i = c0 + (live ? lane : 0);
-        gid = live ? A.chain_state[i] : 0;
+        gid = A.chain_state[i];          // idle lanes read the column of the chain's first state: one that has scores
         a0 = live ? A.chain_band[i] : -INFINITY;
         a1 = live ? A.chain_band[A.total_chain + i] : -INFINITY;
         a2 = live ? A.chain_band[2 * A.total_chain + i] : -INFINITY;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(128) void lsr_viterbi_wide_kernel(vit_args A) {
         n = (int)(A.chain_off[b + 1] - c0);
         const bool live = tid < n;
         const int64_t i = c0 + (live ? tid : 0);
-        gid = live ? A.chain_state[i] : 0;
+        gid = A.chain_state[i];          // idle threads read the column of the chain's first state
         a0 = live ? A.chain_band[i] : -INFINITY;
         a1 = live ? A.chain_band[A.total_chain + i] : -INFINITY;
         a2 = live ? A.chain_band[2 * A.total_chain + i] : -INFINITY;

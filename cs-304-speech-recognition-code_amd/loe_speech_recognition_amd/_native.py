@@ -78,6 +78,7 @@ def _declare(lib) -> None:
         "lsr_labels_from_paths": (c_int, [P, P, P, c_int, P, P, c_int]),
         "lsr_ll_stride": (c_int, [P]),
         "lsr_decode_chain_batch_wide": (c_int, [P, P, P, c_int, c_int64, c_int, P, c_int64, P, P, P, P, P]),
+        "lsr_chain_emission_mode": (c_int, [P, c_int]),
         "lsr_emission_batch": (c_int, [P, P, c_int64, P]),
         "lsr_decode_loop_batch": (c_int, [P, P, P, c_int, c_int64, c_int, P, P, P, P, c_int]),
         "lsr_decode_loop_sweep": (c_int, [P, P, P, c_int, c_int64, c_int, POINTER(c_double), POINTER(c_int32), c_int,
@@ -107,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "lsr_recognize_host", "lsr_recognize_host_timing", "lsr_upload_host", "lsr_download_host", "lsr_shard_bounds", "lsr_comm_get_unique_id", "lsr_comm_init",
     "lsr_comm_destroy", "lsr_allgather_labels", "lsr_allreduce_stats", "lsr_label_record_bytes",
     "lsr_host_pack_label_records", "lsr_host_unpack_label_records", "lsr_pack_label_records", "lsr_unpack_label_records",
-    "lsr_labels_from_paths", "lsr_ll_stride", "lsr_decode_chain_batch_wide",
+    "lsr_labels_from_paths", "lsr_ll_stride", "lsr_decode_chain_batch_wide", "lsr_chain_emission_mode",
 ]
 
 
@@ -277,6 +278,21 @@ class Engine:
         self._check(self.lib.lsr_download_host(self.ctx, self._ptr(tensor), nbytes, c_void_p(out.ctypes.data), 0, 0))
         return out
 
+    def to_host_pinned(self, tensor) -> np.ndarray:
+        """NumPy copy of a small device tensor through a pinned staging buffer that is kept between calls
+        (no pageable bounce buffer, no allocation per call); the result is a fresh array."""
+        if not tensor.is_cuda:
+            return tensor.numpy().copy()
+        t = self.torch
+        n = tensor.numel()
+        stage = self.__dict__.get("_pinned_stage")
+        if stage is None or stage.dtype != tensor.dtype or stage.numel() < n:
+            stage = t.empty((max(n, 1),), dtype=tensor.dtype, pin_memory=True)
+            self.__dict__["_pinned_stage"] = stage
+        stage[:n].copy_(tensor.reshape(-1), non_blocking=True)
+        t.cuda.current_stream(self.device).synchronize()
+        return stage[:n].numpy().reshape(tuple(tensor.shape)).copy()
+
     def audio_batch(self, signals: Sequence[np.ndarray]) -> AudioBatch:
         if len(signals) == 0:
             raise ValueError("empty batch")
@@ -320,12 +336,15 @@ class Engine:
 
     # -- model / graph ----------------------------------------------------------------------------
     def set_model(self, token, mean: np.ndarray, whiten: np.ndarray, log_norm: np.ndarray,
-                  log_weights: Optional[np.ndarray] = None, n_mix: int = 1, triangular: Optional[bool] = None) -> None:
+                  log_weights: Optional[np.ndarray] = None, n_mix: int = 1, rotated: Optional[np.ndarray] = None,
+                  triangular: Optional[bool] = None) -> None:
         """Upload stacked Gaussians.  By default the whitening matrices are first rotated to lower
         triangular form: U^T = Q R gives L = R^T with L L^T = U U^T, so |(x - mu) L|^2 is the same
         Mahalanobis distance (an orthogonal change of basis of the whitened vector) while the
         device skips the 4 x 4 blocks that are structurally zero (55 instead of 100 per state).
-        ``triangular=False`` (or LSR_DENSE_WHITEN=1) uploads SciPy's U unchanged."""
+        ``rotated`` hands in those L when the caller already has them (the batch factorisation of a
+        training step makes them in the same pass).  ``triangular=False`` (or LSR_DENSE_WHITEN=1)
+        uploads SciPy's U unchanged."""
         if token is not None and token == self._model_token:
             return
         if triangular is None:
@@ -336,7 +355,10 @@ class Engine:
             # callers that alternate between a few models (a loop decoder and an isolated-word collection, say)
             # switch tokens on every call: the rotation of a token's matrices is kept, only the upload repeats
             cached = self._rotated.get(token) if token is not None else None
-            if cached is None:
+            if cached is None and rotated is not None:
+                cached = np.ascontiguousarray(rotated, dtype=np.float64)
+                assert cached.shape == whiten.shape
+            elif cached is None:
                 cached = np.tril(np.swapaxes(np.linalg.qr(np.swapaxes(whiten, 1, 2), mode="r"), 1, 2))      # batched
                 if token is not None:
                     if len(self._rotated) >= 8:
@@ -486,6 +508,13 @@ class Engine:
                                                          self._ptr(scores), self._ptr(paths), self._ptr(labels),
                                                          self._ptr(n_labels), labels.shape[1]))
         return out
+
+    CHAIN_EMISSION = {"auto": 0, "all": 1, "reachable": 2}
+
+    def chain_emission_mode(self, mode: str) -> None:
+        """Emission scores computed ahead of a chain decode: every state ("all"), only the states the chains
+        of a 64-frame tile can visit ("reachable"), or the library's choice ("auto", the default)."""
+        self._check(self.lib.lsr_chain_emission_mode(self.ctx, self.CHAIN_EMISSION[mode]))
 
     def decode_chain(self, fb: FeatureBatch, chain_off: np.ndarray, chain_state: np.ndarray, chain_band: np.ndarray,
                      chain_start: np.ndarray, want_paths: bool = True, want_final: bool = False):

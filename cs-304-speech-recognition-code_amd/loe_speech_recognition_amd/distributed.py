@@ -154,6 +154,32 @@ def all_reduce_stats(stats):
     return stats
 
 
+def all_gather_strided(rows: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """Complete a float64 [n, k] table of which every rank filled rows rank, rank + world, ...: one all-gather
+    of the ranks' own rows (padded to the same count), returned in row order on every rank.  Bits travel
+    unchanged (no arithmetic on the way).  Device tensors carry the exchange under the "nccl" backend."""
+    import torch
+
+    dist = _dist()
+    n, k = rows.shape
+    per = (n + world - 1) // world
+    mine = np.zeros((per, k), dtype=np.float64)
+    own = rows[rank::world]
+    mine[:own.shape[0]] = own
+    send = torch.from_numpy(mine)
+    on_device = dist.get_backend() == "nccl"
+    if on_device:
+        send = send.cuda()
+    recv = torch.empty((world * per, k), dtype=torch.float64, device=send.device)
+    dist.all_gather_into_tensor(recv, send)
+    got = (recv.cpu() if on_device else recv).numpy().reshape(world, per, k)
+    out = np.empty((n, k), dtype=np.float64)
+    for r in range(world):
+        cnt = len(range(r, n, world))
+        out[r::world] = got[r, :cnt]
+    return out
+
+
 def gather_label_records(labels, n_labels, n_total: int):
     """All ranks' fixed-width label records in global utterance order.
 

@@ -46,6 +46,9 @@ class MultivariateNormal:
     mean: np.ndarray = field(init=False)
     whiten: np.ndarray = field(init=False)
     log_pdet: float = field(init=False)
+    # lower-triangular L with L L^T = U U^T (the form the device multiplies by), when the factorisation that made
+    # this object also produced it; otherwise the engine derives it from ``whiten`` at upload time
+    tri: Optional[np.ndarray] = field(init=False, default=None, repr=False, compare=False)
 
     @classmethod
     def from_means_covariances(cls, mean: np.ndarray, covariance: np.ndarray) -> "MultivariateNormal":
@@ -106,6 +109,84 @@ class GaussianMixture:
         return eng.emission(fb)[0, 0].cpu().numpy()[()]
 
 
+def _host_threads() -> int:
+    """Threads for host-side batch work: the job's CPU share (OMP_NUM_THREADS on a shared machine, where
+    os.cpu_count() shows every CPU), at most 16."""
+    n = os.cpu_count() or 1
+    v = os.environ.get("OMP_NUM_THREADS", "")
+    if v.isdigit() and int(v) > 0:
+        n = min(n, int(v))
+    return max(1, min(n, 16))
+
+
+def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Optional[int] = None,
+                       shard: Optional[Tuple[int, int]] = None) -> List[MultivariateNormal]:
+    """``[MultivariateNormal.from_means_covariances(m, c) for m, c in zip(means, covariances)]`` as one batch
+    (hidden_markov_model.py:283-292 builds one frozen SciPy distribution per state, one after the other).
+
+    The eigendecompositions run on a pool of threads inside the helper extension, through the very LAPACK
+    routine scipy.linalg.eigh calls (``dsyevr`` with the workspace sizes of its own query, taken from
+    ``scipy.linalg.cython_lapack``), so eigenvalues and whitening matrices carry the bits of the serial path;
+    scipy.linalg.eigh itself holds the GIL for the whole LAPACK call and cannot be spread over threads.  The
+    triangular factor the device uses (``numpy.linalg.qr`` of the transposed whitening matrix) comes out of
+    the same pass.  Errors are raised for the first failing state, with the serial path's exception types.
+
+    ``shard = (rank, world)``: this process factors states rank, rank + world, ... and the results of all
+    processes are exchanged with one all-gather (every process must make the same call)."""
+    import scipy.linalg.cython_lapack as lapack
+
+    from . import _lsr_pyhelper as H          # built by the Makefile next to this file
+
+    cov = np.ascontiguousarray(covariances, dtype=np.float64)
+    means = np.asarray(means, dtype=np.float64)
+    S, d = means.shape
+    assert cov.shape == (S, d, d)
+    finite = np.isfinite(cov).all(axis=(1, 2))
+    first, step = (0, 1) if shard is None or shard[1] <= 1 else shard
+    lam = np.zeros((S, d))
+    whiten = np.zeros((S, d, d))
+    tri = np.zeros((S, d, d))
+    status = np.zeros(S, dtype=np.int32)
+    # a matrix with NaN or infinite entries never reaches LAPACK (scipy.linalg.eigh(check_finite=True))
+    safe = cov if finite.all() else np.where(finite[:, None, None], cov, np.eye(d))
+    caps = lapack.__pyx_capi__
+    H.factor_batch(caps["dsyevr"], caps["dgeqrf"], np.ascontiguousarray(safe), lam, whiten, tri, status, S, d, first, step,
+                   threads or _host_threads())
+    if step > 1:
+        from .distributed import all_gather_strided
+
+        packed = np.concatenate([lam, whiten.reshape(S, -1), tri.reshape(S, -1), status[:, None].astype(np.float64)], axis=1)
+        packed = all_gather_strided(packed, first, step)
+        lam, whiten = packed[:, :d], packed[:, d:d + d * d].reshape(S, d, d)
+        tri, status = packed[:, d + d * d:d + 2 * d * d].reshape(S, d, d), packed[:, -1].astype(np.int32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        eps = 1e6 * np.finfo("d").eps * np.max(np.abs(lam), axis=1)
+        log_pdet = np.sum(np.log(lam), axis=1)
+    out: List[MultivariateNormal] = []
+    for s in range(S):
+        if not finite[s]:
+            raise ValueError("array must not contain infs or NaNs")
+        if status[s] != 0:
+            raise np.linalg.LinAlgError(f"LAPACK reported an error in the eigendecomposition of state {s} (info {status[s]})")
+        if np.min(lam[s]) < -eps[s]:
+            raise ValueError("The input matrix must be symmetric positive semidefinite.")
+        if not (lam[s] > eps[s]).all():
+            raise np.linalg.LinAlgError(
+                "When `allow_singular is False`, the input matrix must be symmetric positive definite.")
+        g = MultivariateNormal()
+        g.mean, g.whiten, g.log_pdet, g.dim_of_features, g.tri = means[s], whiten[s], float(log_pdet[s]), d, tri[s]
+        out.append(g)
+    return out
+
+
+def stack_rotated(gaussians: Sequence) -> Optional[np.ndarray]:
+    """Stacked triangular factors of Gaussians that all carry one (see MultivariateNormal.tri), else None."""
+    flat = [c for g in gaussians for c in (g.components if isinstance(g, GaussianMixture) else [g])]
+    if not flat or any(getattr(g, "tri", None) is None for g in flat):
+        return None
+    return np.stack([g.tri for g in flat])
+
+
 def stack_gaussians(gaussians: Sequence) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Optional[np.ndarray], int]:
     """Flat float64 arrays for lsr_model_upload: (mean, whiten, log_norm, log_weights, n_mix).
     Mixtures contribute their components consecutively."""
@@ -158,7 +239,8 @@ class HiddenMarkovModel:
         cache = self.__dict__.get("_dev_cache")
         if cache is None or cache["n"] != len(self._multivariate_normals) or cache["src"] is not self._multivariate_normals:
             cache = {"token": _native.new_token(), "n": len(self._multivariate_normals),
-                     "src": self._multivariate_normals, "arrays": stack_gaussians(self._multivariate_normals)}
+                     "src": self._multivariate_normals,
+                     "arrays": stack_gaussians(self._multivariate_normals) + (stack_rotated(self._multivariate_normals),)}
             self.__dict__["_dev_cache"] = cache
         return cache["token"], cache["arrays"]
 
@@ -337,9 +419,9 @@ class HiddenMarkovModelTrainable(HiddenMarkovModel):
         self._means = new_means
         d = self._covariances.shape[1]
         with np.errstate(invalid="ignore", divide="ignore"):
-            for s in range(count.shape[0]):
-                cov = (sum_xx[s] - count[s] * np.outer(mean64[s], mean64[s])) / (count[s] - 1)
-                self._covariances[s] = (cov + np.eye(d) * 0.001).astype(np.float32)
+            n = count[:, None, None]
+            cov = (sum_xx - n * (mean64[:, :, None] * mean64[:, None, :])) / (n - 1)
+            self._covariances = (cov + np.eye(d) * 0.001).astype(np.float32)
             probs = (trans_counts / np.sum(trans_counts, axis=1, keepdims=True)).astype(np.float32)
         self._transition_probs = TransitionProbabilities.from_transition_probability(probs)
 
@@ -390,7 +472,7 @@ class HiddenMarkovModelTrainable(HiddenMarkovModel):
 
     @staticmethod
     def get_multivariate_normals(means: np.ndarray, covariances: np.ndarray) -> List[MultivariateNormal]:
-        return [MultivariateNormal.from_means_covariances(mean=m, covariance=c) for m, c in zip(means, covariances)]
+        return factor_covariances(means, covariances)
 
     def _arrays_to_save(self) -> Dict[str, np.ndarray]:
         out = super()._arrays_to_save()
@@ -618,6 +700,9 @@ class HiddenMarkovModelTrainContinuous:
     _trainable_models: Dict[str, HiddenMarkovModelTrainable] = field(default_factory=dict)
     _models_loaded: List[str] = field(default_factory=list)
     _num_of_finished_models: int = field(default=0)
+    # with several ranks: deal the per-state factorisation of the M-step out over the ranks (else every rank
+    # factors every state)
+    shard_factorization: bool = field(default=True)
 
     @classmethod
     def from_folder(cls, folder_path: str, models_to_load: List[str]):
@@ -741,7 +826,7 @@ class HiddenMarkovModelTrainContinuous:
         eng = _native.get_engine()
         t = eng.torch
         models = [self._trainable_models[lab] for lab in self._models_loaded]
-        eng.set_model(_native.new_token(), *stack_gaussians([g for m in models for g in m._multivariate_normals]))
+        eng.set_model(_native.new_token(), *self._stacked_gaussians(models))
         cache = self.__dict__.get("_chain_cache")
         layout = tuple((lab, self._trainable_models[lab].num_of_states) for lab in self._models_loaded)
         if cache is None or cache["owner"] is not owner or cache["layout"] != layout or "d_ids" not in cache:
@@ -783,7 +868,7 @@ class HiddenMarkovModelTrainContinuous:
         count, sum_x, sum_xx = eng.accumulate_stats(fb.feats, slots, fb.total_frames, n_total)
         stats = t.cat([count, sum_x.reshape(-1), sum_xx.reshape(-1), trans.reshape(-1).to(t.float64)])
         stats = all_reduce_stats(stats)
-        stats = stats.cpu().numpy()
+        stats = eng.to_host_pinned(stats)
         d = _native.DIM
         count = stats[:n_total]
         sum_x = stats[n_total:n_total * (1 + d)].reshape(n_total, d)
@@ -792,19 +877,71 @@ class HiddenMarkovModelTrainContinuous:
         base, _ = self._layout()
         self._m_steps(base, count, sum_x, sum_xx, trans)
 
+    def _stacked_gaussians(self, models: Sequence[HiddenMarkovModelTrainable]):
+        """Arguments of Engine.set_model for the Gaussians of all word models in layout order.  After an
+        iteration of this trainer the stacked arrays of the batch factorisation are still at hand (and
+        include the triangular factors); otherwise they are gathered from the models' objects."""
+        cache = self.__dict__.get("_stack_cache")
+        lists = [m._multivariate_normals for m in models]
+        if cache is not None and len(cache["lists"]) == len(lists) and all(a is b for a, b in zip(cache["lists"], lists)):
+            return cache["arrays"]
+        flat = [g for lst in lists for g in lst]
+        return stack_gaussians(flat) + (stack_rotated(flat),)
+
+    def _refresh_inference_weights(self, models: Sequence[HiddenMarkovModelTrainable]) -> None:
+        """``_update_inference_weights`` of several word models at once (hidden_markov_model.py:283-292, 766-767):
+        the log transition stores per model, the Gaussians of all their states as ONE batch factorisation on
+        the host threads - and, when several ranks train together, with the states dealt out over the ranks
+        (rank r factors states r, r + world, ...; one all-gather of the factors), so that the host work of an
+        iteration divides by the number of ranks like the device work does."""
+        if not models:
+            return
+        for m in models:
+            m._log_transition_probs = LogTransitionProbabilities.from_transition_probability(m._transition_probs)
+        means = np.concatenate([m._means for m in models], axis=0)
+        covs = np.concatenate([m._covariances for m in models], axis=0)
+        from .distributed import is_active, rank_world
+
+        shard = rank_world() if self.shard_factorization and is_active() else None
+        gaussians = factor_covariances(means, covs, shard=shard)
+        lo = 0
+        for m in models:
+            m._multivariate_normals = gaussians[lo:lo + m._means.shape[0]]
+            lo += m._means.shape[0]
+        if [m.label for m in models] == list(self._models_loaded):
+            d = means.shape[1]
+            log_norm = np.array([g.log_norm for g in gaussians], dtype=np.float64)
+            # rows of the gaussians are views of these stacks: nothing is copied
+            self.__dict__["_stack_cache"] = {
+                "lists": [m._multivariate_normals for m in models],
+                "arrays": (np.stack([g.mean for g in gaussians]), np.stack([g.whiten for g in gaussians]), log_norm, None, 1,
+                           np.stack([g.tri for g in gaussians]))}
+
     def _m_steps(self, base, count, sum_x, sum_xx, trans) -> None:
-        """hidden_markov_model.py:754-770, including the never-reset convergence counter."""
+        """hidden_markov_model.py:754-770, including the never-reset convergence counter: a model whose means
+        did not move counts as finished every time, and the iteration that brings the counter to the number of
+        models ends the training at that model (the models after it keep their parameters).  The reference
+        refreshes a model's inference weights in a ``finally`` right after its update; here the models that
+        were reached are refreshed together afterwards (_refresh_inference_weights)."""
+        reached: List[HiddenMarkovModelTrainable] = []
+        stop: Optional[BaseException] = None
         for lab in self._models_loaded:
             m = self._trainable_models[lab]
             lo, hi = base[lab], base[lab] + m.num_of_states
+            reached.append(m)
             try:
                 m._m_step(count[lo:hi], sum_x[lo:hi], sum_xx[lo:hi], trans[lo:hi, lo:hi])
-            except HiddenMarkovModelTrainable.HMMTrainConverge:
+            except HiddenMarkovModelTrainable.HMMTrainConverge as e:
                 self._num_of_finished_models += 1
                 if self._num_of_finished_models == len(self._trainable_models):
-                    raise
-            finally:
-                m._update_inference_weights()
+                    stop = e
+                    break
+            except HiddenMarkovModelTrainable.HMMTrainMeanFail as e:
+                stop = e
+                break
+        self._refresh_inference_weights(reached)
+        if stop is not None:
+            raise stop
 
     def train(self, labeled_mfccs: Dict[str, List[np.ndarray]], max_iterations: int = 100) -> None:
         bar = tqdm(total=max_iterations, desc="Training Iteration", disable=not self.isTqdm, position=0)

@@ -247,6 +247,20 @@ int lsr_decode_chain_batch_wide(lsr_ctx* ctx, const float* feats_d, const int64_
                                 const int32_t* chain_state_d, const float* chain_band_d,
                                 const uint8_t* chain_start_d, float* scores_d, int8_t* paths_d);
 
+/* Which emission scores lsr_decode_chain_batch[_wide] computes before the recursion.  A chain only reads the
+ * columns of its own states for the frames of its own utterance (hidden_markov_model.py:638-664 builds the
+ * forced-alignment model S d S d ... S from the models of the utterance's words only, so the reference never
+ * evaluates the other words' Gaussians there either).  LSR_CHAIN_EMISSION_REACHABLE scores, per 64-frame tile,
+ * the union of the states of the chains whose utterances own frames of the tile; LSR_CHAIN_EMISSION_ALL scores
+ * every state of the model; LSR_CHAIN_EMISSION_AUTO (default) takes REACHABLE when the chains hold on average
+ * fewer than three quarters of the model's states (chains that span the whole model, like the side-by-side
+ * isolated models of ModelCollection.predict, gain nothing).  Scores, paths and last-frame tables are the same
+ * bits either way.  Mixture models always take ALL. */
+#define LSR_CHAIN_EMISSION_AUTO 0
+#define LSR_CHAIN_EMISSION_ALL 1
+#define LSR_CHAIN_EMISSION_REACHABLE 2
+int lsr_chain_emission_mode(lsr_ctx* ctx, int mode);
+
 /* The penalty sweep of scripts/project5_find_trans_ndigits_with_sil.py:71-88 (the same
  * utterances decoded once per candidate between-word log-probability) as one call: emission scores
  * are computed once and the loop decoder runs once per entry of between[n_between] (host array;
