@@ -243,9 +243,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
 // ---- scores of selected states only ------------------------------------------------------------------------
 // Forced alignment reads, for the frames of an utterance, only the columns of the states in that utterance's
 // chain (hidden_markov_model.py:638-664: the chain S d S d ... S holds the models of the utterance's own words).
-// tile_mask[t] (two 64-bit words) holds the states any utterance overlapping frames 64 t .. 64 t + 63 can
-// visit, pair_off the running count of set bits.  The work list is the (tile, selected state) pairs in tile
-// order, cut into equal contiguous shares like the full kernel's; columns outside the mask are left as they are.
+// Here the 64-frame tiles are anchored at the utterance starts (tile k of utterance b = its frames 64 k ..
+// 64 k + 63), so a tile belongs to one utterance and needs exactly the states of that utterance's chain:
+// utt_mask[b] (two 64-bit words).  The work list is every (utterance, tile, selected state) in that order -
+// utterance b owns pairs pair_first[b] .. pair_first[b + 1] - 1 - cut into equal contiguous shares like the
+// full kernel's.  Columns outside the mask are left as they are.
+
 // a wave-uniform 64-bit value moved to scalar registers
 __device__ __forceinline__ unsigned long long em_uniform(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -256,48 +259,65 @@ template <bool TRI>
 __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
     const double* __restrict__ lognorm, float* __restrict__ ll, int ll_stride,
-    const unsigned long long* __restrict__ tile_mask, const int64_t* __restrict__ pair_off) {
+    const int64_t* __restrict__ frame_off, int n_utts, const unsigned long long* __restrict__ utt_mask,
+    const int64_t* __restrict__ pair_first) {
     __shared__ float tile[EM_WAVES][64][EM_RUN];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = lane & 15, grp = lane >> 4;
-    const int64_t n_tiles = (total_frames + 63) / 64;
-    const int64_t n_pairs = (int64_t)em_uniform((unsigned long long)pair_off[n_tiles]);
+    const int64_t n_pairs = (int64_t)em_uniform((unsigned long long)pair_first[n_utts]);
     const int64_t n_waves = (int64_t)gridDim.x * EM_WAVES, me = (int64_t)blockIdx.x * EM_WAVES + wave;
     int64_t p = (int64_t)em_uniform((unsigned long long)(me * n_pairs / n_waves));
     const int64_t p_end = (int64_t)em_uniform((unsigned long long)((me + 1) * n_pairs / n_waves));
     if (p >= p_end) return;
 
-    // the tile that holds pair p: the last one whose running count is <= p
-    int64_t t = 0;
+    // the utterance that owns pair p: the last one whose first pair is <= p (utterances without pairs in between
+    // share that value and are passed over)
+    int b = 0;
     {
-        int64_t hi = n_tiles;
-        while (hi - t > 1) {
-            const int64_t mid = (t + hi) >> 1;
-            if ((int64_t)em_uniform((unsigned long long)pair_off[mid]) <= p) t = mid; else hi = mid;
+        int hi = n_utts;
+        while (hi - b > 1) {
+            const int mid = (b + hi) >> 1;
+            if ((int64_t)em_uniform((unsigned long long)pair_first[mid]) <= p) b = mid; else hi = mid;
         }
     }
-    // states of tile t not yet scored
-    unsigned long long m0 = em_uniform(tile_mask[2 * t]), m1 = em_uniform(tile_mask[2 * t + 1]);
-    for (int64_t skip = p - (int64_t)em_uniform((unsigned long long)pair_off[t]); skip > 0; --skip) {
-        if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+    unsigned long long u0 = em_uniform(utt_mask[2 * b]), u1 = em_uniform(utt_mask[2 * b + 1]);     // states of utterance b
+    int64_t f_utt = (int64_t)em_uniform((unsigned long long)frame_off[b]);
+    int T = (int)((int64_t)em_uniform((unsigned long long)frame_off[b + 1]) - f_utt);
+    int k;                                                   // tile within the utterance
+    unsigned long long m0 = u0, m1 = u1;                     // states of that tile not yet scored
+    {
+        const int per_tile = __popcll(u0) + __popcll(u1);
+        const int64_t local = p - (int64_t)em_uniform((unsigned long long)pair_first[b]);
+        k = (int)(local / per_tile);
+        for (int skip = (int)(local - (int64_t)k * per_tile); skip > 0; --skip) {
+            if (m0) m0 &= m0 - 1; else m1 &= m1 - 1;
+        }
     }
 
-    int64_t loaded = -1;
+    int64_t loaded = -1;                                     // first frame of the tile whose frames are in x[][]
     double x[4][LSR_KSTEPS];
     while (p < p_end) {
-        if ((m0 | m1) == 0) {                 // tile finished (p < p_end <= n_pairs: a later tile has states left)
-            ++t;
-            m0 = em_uniform(tile_mask[2 * t]);
-            m1 = em_uniform(tile_mask[2 * t + 1]);
+        if ((m0 | m1) == 0) {                 // tile finished (p < p_end <= n_pairs: some later tile has states left)
+            if (64 * (++k) >= T) {            // utterance finished
+                ++b;
+                u0 = em_uniform(utt_mask[2 * b]);
+                u1 = em_uniform(utt_mask[2 * b + 1]);
+                f_utt = (int64_t)em_uniform((unsigned long long)frame_off[b]);
+                T = (int)((int64_t)em_uniform((unsigned long long)frame_off[b + 1]) - f_utt);
+                k = T > 0 ? 0 : -1;           // an utterance without frames has no tile: the test above moves on
+            }
+            m0 = k >= 0 ? u0 : 0;
+            m1 = k >= 0 ? u1 : 0;
             continue;
         }
         int cnt = __popcll(m0) + __popcll(m1);
         if (cnt > EM_RUN) cnt = EM_RUN;
         if ((int64_t)cnt > p_end - p) cnt = (int)(p_end - p);
         p += cnt;
-        const int64_t f0 = t * 64;
-        if (t != loaded) {
-            loaded = t;
+        const int64_t f0 = f_utt + 64 * (int64_t)k;
+        const int n_rows = T - 64 * k < 64 ? T - 64 * k : 64;          // rows of the tile that belong to the utterance
+        if (f0 != loaded) {
+            loaded = f0;
             em_load_frames(x, feats, f0, total_frames, col, grp);
         }
 
@@ -338,8 +358,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < cnt) {
-#pragma unroll 8
-            for (int r = 0; r < 64; ++r)
+            for (int r = 0; r < n_rows; ++r)
                 ll[(f0 + r) * ll_stride + my_col] = tile[wave][r][(lane ^ r) & (EM_RUN - 1)];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -348,10 +367,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
     }
 }
 
-// states visited by the chain of each utterance: one wavefront per utterance
+// states visited by the chain of each utterance and the number of (tile, state) pairs it owns: one wavefront
+// per utterance
 __global__ __launch_bounds__(64) void lsr_chain_utt_mask_kernel(const int64_t* __restrict__ chain_off,
                                                                 const int32_t* __restrict__ chain_state, int n_cols,
-                                                                unsigned long long* __restrict__ utt_mask) {
+                                                                const int64_t* __restrict__ frame_off,
+                                                                unsigned long long* __restrict__ utt_mask,
+                                                                int32_t* __restrict__ utt_pairs) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t c0 = chain_off[b], c1 = chain_off[b + 1];
     unsigned long long m0 = 0, m1 = 0;
@@ -368,36 +390,13 @@ __global__ __launch_bounds__(64) void lsr_chain_utt_mask_kernel(const int64_t* _
     if (lane == 0) {
         utt_mask[2 * b] = m0;
         utt_mask[2 * b + 1] = m1;
+        const int64_t T = frame_off[b + 1] - frame_off[b];
+        utt_pairs[b] = T > 0 ? (int32_t)((T + 63) / 64) * (__popcll(m0) + __popcll(m1)) : 0;
     }
 }
 
-// union of the utterance masks over the utterances that own frames of each 64-frame tile: one thread per tile
-__global__ __launch_bounds__(256) void lsr_chain_tile_mask_kernel(const int64_t* __restrict__ frame_off, int n_utts,
-                                                                  int64_t total_frames,
-                                                                  const unsigned long long* __restrict__ utt_mask,
-                                                                  unsigned long long* __restrict__ tile_mask,
-                                                                  int32_t* __restrict__ tile_count) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n_tiles = (total_frames + 63) / 64;
-    if (t >= n_tiles) return;
-    const int64_t f0 = t * 64, f1 = f0 + 64 < total_frames ? f0 + 64 : total_frames;
-    int lo = 0, hi = n_utts;                          // last utterance that starts at or before f0
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (frame_off[mid] <= f0) lo = mid; else hi = mid;
-    }
-    unsigned long long m0 = 0, m1 = 0;
-    for (int b = lo; b < n_utts && frame_off[b] < f1; ++b) {
-        m0 |= utt_mask[2 * b];
-        m1 |= utt_mask[2 * b + 1];
-    }
-    tile_mask[2 * t] = m0;
-    tile_mask[2 * t + 1] = m1;
-    tile_count[t] = __popcll(m0) + __popcll(m1);
-}
-
-// exclusive running sum of the tile counts (one workgroup: every thread a contiguous piece, the pieces' totals
-// scanned in LDS); out has n + 1 entries
+// exclusive running sum of the utterances' pair counts (one workgroup: every thread a contiguous piece, the
+// pieces' totals scanned in LDS); out has n + 1 entries
 __global__ __launch_bounds__(1024) void lsr_chain_scan_kernel(const int32_t* __restrict__ count, int64_t n,
                                                               int64_t* __restrict__ out) {
     __shared__ int64_t part[1024];
@@ -446,28 +445,26 @@ int lsr_launch_emission_chains(lsr_ctx* ctx, const float* feats_d, int64_t total
                                const int32_t* chain_state_d) {
     if (ctx->n_mix > 1) return lsr_launch_emission(ctx, feats_d, total_frames, ll_d);      // mixtures: all states
     const int n_cols = ctx->n_states;
-    const int64_t n_tiles = (total_frames + 63) / 64;
-    // [utterance masks 16 B][tile masks 16 B][running counts 8 B x (tiles + 1)][tile counts 4 B]
-    const size_t need = (size_t)n_utts * 16 + (size_t)n_tiles * 16 + (size_t)(n_tiles + 1) * 8 + (size_t)n_tiles * 4;
+    // [utterance masks 16 B][first pair of each utterance 8 B x (utterances + 1)][pairs of each utterance 4 B]
+    const size_t need = (size_t)n_utts * 16 + (size_t)(n_utts + 1) * 8 + (size_t)n_utts * 4;
     int rc = lsr_reserve(ctx, &ctx->ws_mask, need, "state masks of the alignment chains");
     if (rc) return rc;
     unsigned long long* utt_mask = (unsigned long long*)ctx->ws_mask.ptr;
-    unsigned long long* tile_mask = utt_mask + (size_t)n_utts * 2;
-    int64_t* pair_off = (int64_t*)(tile_mask + (size_t)n_tiles * 2);
-    int32_t* tile_count = (int32_t*)(pair_off + n_tiles + 1);
+    int64_t* pair_first = (int64_t*)(utt_mask + (size_t)n_utts * 2);
+    int32_t* utt_pairs = (int32_t*)(pair_first + n_utts + 1);
     lsr_prof_begin(ctx, LSR_K_EMISSION);
     hipLaunchKernelGGL(lsr_chain_utt_mask_kernel, dim3((unsigned)n_utts), dim3(64), 0, ctx->stream, chain_off_d,
-                       chain_state_d, n_cols, utt_mask);
-    hipLaunchKernelGGL(lsr_chain_tile_mask_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream,
-                       frame_off_d, n_utts, total_frames, utt_mask, tile_mask, tile_count);
-    hipLaunchKernelGGL(lsr_chain_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_count, n_tiles, pair_off);
-    // the number of pairs is only known on the device: the full persistent grid, surplus wavefronts leave at once
-    int64_t blocks = (n_tiles * n_cols + EM_WAVES - 1) / EM_WAVES;
+                       chain_state_d, n_cols, frame_off_d, utt_mask, utt_pairs);
+    hipLaunchKernelGGL(lsr_chain_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, utt_pairs, (int64_t)n_utts, pair_first);
+    // the number of pairs is only known on the device: the full persistent grid (at most one wavefront per pair of
+    // the all-states form), surplus wavefronts leave at once
+    int64_t blocks = (((total_frames + 63) / 64 + n_utts) * n_cols + EM_WAVES - 1) / EM_WAVES;
     if (blocks > 3 * (int64_t)ctx->n_cus) blocks = 3 * (int64_t)ctx->n_cus;
-    void (*kern)(const float*, int64_t, const double*, const double*, float*, int, const unsigned long long*, const int64_t*) =
+    void (*kern)(const float*, int64_t, const double*, const double*, float*, int, const int64_t*, int,
+                 const unsigned long long*, const int64_t*) =
         ctx->whiten_triangular ? lsr_emission_masked_kernel<true> : lsr_emission_masked_kernel<false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * EM_WAVES), 0, ctx->stream, feats_d, total_frames,
-                       ctx->d_wfrag, ctx->d_lognorm, ll_d, lsr_ctx_ll_stride(ctx), tile_mask, pair_off);
+                       ctx->d_wfrag, ctx->d_lognorm, ll_d, lsr_ctx_ll_stride(ctx), frame_off_d, n_utts, utt_mask, pair_first);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_emission_masked_kernel");
     return LSR_OK;

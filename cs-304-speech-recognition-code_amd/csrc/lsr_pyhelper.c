@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 /* clip_table(seq, ptrs, lens) -> int
  * seq: sequence of arrays; ptrs: writable uint64[n] buffer; lens: writable int64[n] buffer.
@@ -123,60 +124,145 @@ struct factor_job {
     const double* cov;
     double *lam, *whiten, *tri;
     int32_t* status;
-    int n, n_mats, first, step, tid, n_threads;
+    int n, n_mats, first, step;
     int lwork, liwork, qwork;
+    int next;            /* next share to hand out (atomic) */
     int failed;          /* allocation failure */
 };
 
-static void* factor_worker(void* arg) {
-    struct factor_job* J = (struct factor_job*)arg;
+/* one matrix with the scratch memory at a (doubles) / iw (ints) */
+static void factor_one(const struct factor_job* J, int i, double* a, int* iw) {
     const int n = J->n;
     const size_t nn = (size_t)n * n;
-    double* a = (double*)malloc(sizeof(double) * (2 * nn + (size_t)J->lwork + (size_t)J->qwork + 2 * (size_t)n));
-    int* iw = (int*)malloc(sizeof(int) * ((size_t)J->liwork + 2 * (size_t)n));
-    if (!a || !iw) {
-        free(a);
-        free(iw);
-        J->failed = 1;
-        return NULL;
-    }
     double *z = a + nn, *work = z + nn, *qw = work + J->lwork, *w = qw + J->qwork, *tau = w + n;
     int *iwork = iw, *isuppz = iw + J->liwork;
-    for (int i = J->first + J->step * J->tid; i < J->n_mats; i += J->step * J->n_threads) {
-        const double* c = J->cov + (size_t)i * nn;
-        /* column-major copy of the row-major matrix: a[r + col * n] = C[r][col] */
-        for (int r = 0; r < n; ++r)
-            for (int col = 0; col < n; ++col) a[r + (size_t)col * n] = c[(size_t)r * n + col];
-        char jobz = 'V', range = 'A', uplo = 'L';
-        int nn_ = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = J->lwork, liwork = J->liwork;
-        double vl = 0.0, vu = 1.0, abstol = 0.0;
-        J->syevr(&jobz, &range, &uplo, &nn_, a, &lda, &vl, &vu, &il, &iu, &abstol, &m, w, z, &ldz, isuppz, work, &lwork,
-                 iwork, &liwork, &info);
-        if (info == 0 && m != n) info = -1000;
-        double* U = J->whiten + (size_t)i * nn;
-        double* L = J->tri + (size_t)i * nn;
-        for (int j = 0; j < n; ++j) {
-            J->lam[(size_t)i * n + j] = w[j];
-            const double scale = sqrt(1.0 / w[j]);
-            for (int k = 0; k < n; ++k) U[(size_t)k * n + j] = z[k + (size_t)j * n] * scale;
-        }
-        if (info == 0) {
-            /* the row-major U read as column-major is U^T: factor it in place of a copy */
-            memcpy(L, U, sizeof(double) * nn);
-            int qinfo = 0, qwork = J->qwork;
-            J->geqrf(&nn_, &nn_, L, &lda, tau, qw, &qwork, &qinfo);
-            if (qinfo != 0) info = -2000 - qinfo;
-            /* R[j][k] (j <= k) sits at L[j + k * n] = row-major L[k][j]: zero what lies above the diagonal of L */
-            for (int k = 0; k < n; ++k)
-                for (int j = k + 1; j < n; ++j) L[(size_t)k * n + j] = 0.0;
-        } else {
-            memset(L, 0, sizeof(double) * nn);
-        }
-        J->status[i] = info;
+    const double* c = J->cov + (size_t)i * nn;
+    /* column-major copy of the row-major matrix: a[r + col * n] = C[r][col] */
+    for (int r = 0; r < n; ++r)
+        for (int col = 0; col < n; ++col) a[r + (size_t)col * n] = c[(size_t)r * n + col];
+    char jobz = 'V', range = 'A', uplo = 'L';
+    int nn_ = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = J->lwork, liwork = J->liwork;
+    double vl = 0.0, vu = 1.0, abstol = 0.0;
+    J->syevr(&jobz, &range, &uplo, &nn_, a, &lda, &vl, &vu, &il, &iu, &abstol, &m, w, z, &ldz, isuppz, work, &lwork, iwork,
+             &liwork, &info);
+    if (info == 0 && m != n) info = -1000;
+    double* U = J->whiten + (size_t)i * nn;
+    double* L = J->tri + (size_t)i * nn;
+    for (int j = 0; j < n; ++j) {
+        J->lam[(size_t)i * n + j] = w[j];
+        const double scale = sqrt(1.0 / w[j]);
+        for (int k = 0; k < n; ++k) U[(size_t)k * n + j] = z[k + (size_t)j * n] * scale;
     }
-    free(a);
-    free(iw);
+    if (info == 0) {
+        /* the row-major U read as column-major is U^T: factor it in place of a copy */
+        memcpy(L, U, sizeof(double) * nn);
+        int qinfo = 0, qwork = J->qwork;
+        J->geqrf(&nn_, &nn_, L, &lda, tau, qw, &qwork, &qinfo);
+        if (qinfo != 0) info = -2000 - qinfo;
+        /* R[j][k] (j <= k) sits at L[j + k * n] = row-major L[k][j]: zero what lies above the diagonal of L */
+        for (int k = 0; k < n; ++k)
+            for (int j = k + 1; j < n; ++j) L[(size_t)k * n + j] = 0.0;
+    } else {
+        memset(L, 0, sizeof(double) * nn);
+    }
+    J->status[i] = info;
+}
+
+/* takes matrices off the job until none are left; scratch memory is the caller's and grows on demand */
+struct factor_scratch {
+    double* a;
+    int* iw;
+    size_t a_len, iw_len;
+};
+
+static void factor_drain(struct factor_job* J, struct factor_scratch* S) {
+    const size_t nn = (size_t)J->n * J->n;
+    const size_t need_a = 2 * nn + (size_t)J->lwork + (size_t)J->qwork + 2 * (size_t)J->n;
+    const size_t need_i = (size_t)J->liwork + 2 * (size_t)J->n;
+    if (S->a_len < need_a) {
+        free(S->a);
+        S->a = (double*)malloc(sizeof(double) * need_a);
+        S->a_len = S->a ? need_a : 0;
+    }
+    if (S->iw_len < need_i) {
+        free(S->iw);
+        S->iw = (int*)malloc(sizeof(int) * need_i);
+        S->iw_len = S->iw ? need_i : 0;
+    }
+    if (!S->a || !S->iw) {
+        __atomic_store_n(&J->failed, 1, __ATOMIC_RELAXED);
+        return;
+    }
+    for (;;) {
+        const int share = __atomic_fetch_add(&J->next, 1, __ATOMIC_RELAXED);
+        const long i = (long)J->first + (long)J->step * share;
+        if (i >= J->n_mats) break;
+        factor_one(J, (int)i, S->a, S->iw);
+    }
+}
+
+/* Worker threads are started once and wait for jobs: starting sixteen threads costs about as much as the
+ * factorisations of a 58-state model take.  A child process after fork() has none of them and starts its own. */
+#define FACTOR_MAX_THREADS 64
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t wake, idle;
+    pthread_t tid[FACTOR_MAX_THREADS];
+    int n_workers;           /* threads started */
+    int wanted;              /* workers that should join the current job */
+    int running;             /* workers still inside the current job */
+    unsigned generation;
+    struct factor_job* job;
+    pid_t pid;
+} pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, NULL, 0};
+
+static void* factor_worker(void* arg) {
+    const int me = (int)(intptr_t)arg;
+    struct factor_scratch S = {NULL, NULL, 0, 0};
+    unsigned seen = 0;
+    pthread_mutex_lock(&pool.mu);
+    for (;;) {
+        while (pool.generation == seen) pthread_cond_wait(&pool.wake, &pool.mu);
+        seen = pool.generation;
+        if (me >= pool.wanted) continue;
+        struct factor_job* J = pool.job;
+        pthread_mutex_unlock(&pool.mu);
+        factor_drain(J, &S);
+        pthread_mutex_lock(&pool.mu);
+        if (--pool.running == 0) pthread_cond_signal(&pool.idle);
+    }
     return NULL;
+}
+
+static pthread_mutex_t call_mu = PTHREAD_MUTEX_INITIALIZER;      /* one factor_batch call at a time */
+
+/* runs the job on the calling thread plus `helpers` pool workers (fewer if threads cannot be started) */
+static void factor_run(struct factor_job* J, int helpers) {
+    static struct factor_scratch mine = {NULL, NULL, 0, 0};       /* callers hold call_mu: one at a time */
+    if (helpers > FACTOR_MAX_THREADS) helpers = FACTOR_MAX_THREADS;
+    pthread_mutex_lock(&pool.mu);
+    if (pool.pid != getpid()) {              /* first use, or a forked child: no workers exist in this process */
+        pool.pid = getpid();
+        pool.n_workers = 0;
+        pool.running = 0;
+    }
+    while (pool.n_workers < helpers) {
+        if (pthread_create(&pool.tid[pool.n_workers], NULL, factor_worker, (void*)(intptr_t)pool.n_workers) != 0) break;
+        pthread_detach(pool.tid[pool.n_workers]);
+        ++pool.n_workers;
+    }
+    if (helpers > pool.n_workers) helpers = pool.n_workers;
+    pool.job = J;
+    pool.wanted = helpers;
+    pool.running = helpers;
+    ++pool.generation;
+    if (helpers > 0) pthread_cond_broadcast(&pool.wake);
+    pthread_mutex_unlock(&pool.mu);
+    factor_drain(J, &mine);
+    pthread_mutex_lock(&pool.mu);
+    while (pool.running > 0) pthread_cond_wait(&pool.idle, &pool.mu);
+    pool.job = NULL;
+    pthread_mutex_unlock(&pool.mu);
 }
 
 static void* capsule_pointer(PyObject* cap) {
@@ -196,8 +282,6 @@ static PyObject* factor_batch(PyObject* self, PyObject* args) {
                           &first, &step, &threads))
         return NULL;
     PyObject* result = NULL;
-    struct factor_job* jobs = NULL;
-    pthread_t* tids = NULL;
     dsyevr_fn syevr = (dsyevr_fn)capsule_pointer(cap_syevr);
     dgeqrf_fn geqrf = syevr ? (dgeqrf_fn)capsule_pointer(cap_geqrf) : NULL;
     if (!syevr || !geqrf) goto done;
@@ -230,45 +314,30 @@ static PyObject* factor_batch(PyObject* self, PyObject* args) {
         if (count < 0) count = 0;
         if (threads < 1) threads = 1;
         if (threads > count) threads = count > 0 ? count : 1;
-        jobs = (struct factor_job*)calloc((size_t)threads, sizeof(struct factor_job));
-        tids = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
-        if (!jobs || !tids) {
-            PyErr_NoMemory();
-            goto done;
-        }
-        for (int t = 0; t < threads; ++t) {
-            struct factor_job* J = &jobs[t];
-            J->syevr = syevr;
-            J->geqrf = geqrf;
-            J->cov = (const double*)cov.buf;
-            J->lam = (double*)lam.buf;
-            J->whiten = (double*)whiten.buf;
-            J->tri = (double*)tri.buf;
-            J->status = (int32_t*)status.buf;
-            J->n = n;
-            J->n_mats = n_mats;
-            J->first = first;
-            J->step = step;
-            J->tid = t;
-            J->n_threads = threads;
-            J->lwork = (int)wq > 1 ? (int)wq : 1;
-            J->liwork = iwq > 1 ? iwq : 1;
-            J->qwork = (int)qq > n ? (int)qq : n;
-        }
-        int failed = 0;
+        struct factor_job J;
+        memset(&J, 0, sizeof(J));
+        J.syevr = syevr;
+        J.geqrf = geqrf;
+        J.cov = (const double*)cov.buf;
+        J.lam = (double*)lam.buf;
+        J.whiten = (double*)whiten.buf;
+        J.tri = (double*)tri.buf;
+        J.status = (int32_t*)status.buf;
+        J.n = n;
+        J.n_mats = n_mats;
+        J.first = first;
+        J.step = step;
+        J.lwork = (int)wq > 1 ? (int)wq : 1;
+        J.liwork = iwq > 1 ? iwq : 1;
+        J.qwork = (int)qq > n ? (int)qq : n;
+        /* the pool and the caller's scratch are process-wide: the GIL is kept until the job has been handed over
+         * and is released while the calling thread works on its share (factor_run) */
         Py_BEGIN_ALLOW_THREADS
-        int started = 0;
-        for (int t = 1; t < threads; ++t) {
-            if (pthread_create(&tids[t], NULL, factor_worker, &jobs[t]) != 0) break;
-            ++started;
-        }
-        factor_worker(&jobs[0]);
-        for (int t = 1; t <= started; ++t) pthread_join(tids[t], NULL);
-        /* shares whose thread could not be started run here */
-        for (int t = started + 1; t < threads; ++t) factor_worker(&jobs[t]);
-        for (int t = 0; t < threads; ++t) failed |= jobs[t].failed;
+        pthread_mutex_lock(&call_mu);
+        factor_run(&J, threads - 1);
+        pthread_mutex_unlock(&call_mu);
         Py_END_ALLOW_THREADS
-        if (failed) {
+        if (J.failed) {
             PyErr_NoMemory();
             goto done;
         }
@@ -276,8 +345,6 @@ static PyObject* factor_batch(PyObject* self, PyObject* args) {
     result = Py_None;
     Py_INCREF(result);
 done:
-    free(jobs);
-    free(tids);
     PyBuffer_Release(&cov);
     PyBuffer_Release(&lam);
     PyBuffer_Release(&whiten);

@@ -151,7 +151,7 @@ def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Opti
     safe = cov if finite.all() else np.where(finite[:, None, None], cov, np.eye(d))
     caps = lapack.__pyx_capi__
     H.factor_batch(caps["dsyevr"], caps["dgeqrf"], np.ascontiguousarray(safe), lam, whiten, tri, status, S, d, first, step,
-                   threads or _host_threads())
+                   threads or min(_host_threads(), 6))
     if step > 1:
         from .distributed import all_gather_strided
 
@@ -162,19 +162,22 @@ def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Opti
     with np.errstate(invalid="ignore", divide="ignore"):
         eps = 1e6 * np.finfo("d").eps * np.max(np.abs(lam), axis=1)
         log_pdet = np.sum(np.log(lam), axis=1)
-    out: List[MultivariateNormal] = []
-    for s in range(S):
+        bad = ~finite | (status != 0) | ~(lam > eps[:, None]).all(axis=1)
+    if bad.any():                     # the first failing state decides, with the error the serial path raises for it
+        s = int(np.argmax(bad))
         if not finite[s]:
             raise ValueError("array must not contain infs or NaNs")
         if status[s] != 0:
             raise np.linalg.LinAlgError(f"LAPACK reported an error in the eigendecomposition of state {s} (info {status[s]})")
         if np.min(lam[s]) < -eps[s]:
             raise ValueError("The input matrix must be symmetric positive semidefinite.")
-        if not (lam[s] > eps[s]).all():
-            raise np.linalg.LinAlgError(
-                "When `allow_singular is False`, the input matrix must be symmetric positive definite.")
+        raise np.linalg.LinAlgError(
+            "When `allow_singular is False`, the input matrix must be symmetric positive definite.")
+    out: List[MultivariateNormal] = []
+    pdet = log_pdet.tolist()
+    for s in range(S):
         g = MultivariateNormal()
-        g.mean, g.whiten, g.log_pdet, g.dim_of_features, g.tri = means[s], whiten[s], float(log_pdet[s]), d, tri[s]
+        g.mean, g.whiten, g.log_pdet, g.dim_of_features, g.tri = means[s], whiten[s], pdet[s], d, tri[s]
         out.append(g)
     return out
 
