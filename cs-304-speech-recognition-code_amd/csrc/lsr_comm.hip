@@ -154,7 +154,8 @@ __global__ void lsr_unpack_records_kernel(const uint8_t* __restrict__ records, i
 extern "C" int lsr_pack_label_records(lsr_ctx* ctx, const uint8_t* labels_d, const int32_t* n_labels_d, int64_t n_local,
                                       int label_cap, int64_t shard_cap, uint8_t* records_d) {
     if (!ctx) return LSR_ERR_ARG;
-    if (!labels_d || !n_labels_d || !records_d || label_cap < 1 || n_local < 0 || n_local > shard_cap || shard_cap < 1)
+    // a rank without utterances (more ranks than utterances) has nothing to point at: its records are all padding
+    if (((!labels_d || !n_labels_d) && n_local != 0) || !records_d || label_cap < 1 || n_local < 0 || n_local > shard_cap || shard_cap < 1)
         return lsr_fail(ctx, LSR_ERR_ARG, "lsr_pack_label_records: bad argument");
     LSR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t piece = (size_t)(shard_cap * lsr_label_record_bytes(label_cap));
@@ -227,7 +228,7 @@ extern "C" int lsr_allgather_labels(lsr_ctx* ctx, const uint8_t* labels_d, const
     if (!ctx) return LSR_ERR_ARG;
     lsr_comm* c = ctx->comm;
     if (!c) return lsr_fail(ctx, LSR_ERR_STATE, "lsr_allgather_labels: call lsr_comm_init first");
-    if (!labels_d || !n_labels_d || !labels_out_d || !n_labels_out_d || label_cap < 1 || n_total < 1)
+    if (((!labels_d || !n_labels_d) && n_local != 0) || !labels_out_d || !n_labels_out_d || label_cap < 1 || n_total < 1)
         return lsr_fail(ctx, LSR_ERR_ARG, "lsr_allgather_labels: bad argument");
     int64_t lo, hi;
     lsr_shard_bounds(n_total, c->rank, c->world, &lo, &hi);

@@ -8,8 +8,11 @@
 // the process ends); its address on a device is resolved once, with that device current, by
 // lsr_noalloc_init (called from lsr_ctx_create) and kept per device.  Host code only ever uses the
 // resolved address: the array's name in host code is a stand-in symbol, not device memory.
-// All calls on one GPU share the array: two calls that overlap in time on one GPU (different
-// streams or contexts) race.
+// All calls on one GPU share the array.  Calls made one after the other from the host - on any stream, through
+// any context of this process - are ordered on the device by an event kept per GPU: a call first makes its
+// stream wait for the event the previous call recorded behind its last kernel.  (Under stream capture the event
+// is left alone: the order of the captured launches is the graph's.)  Calls issued CONCURRENTLY from several host
+// threads, or from several processes sharing the GPU, still race.
 #include "lsr_internal.h"
 
 #define NA_ALIGN(x) (((x) + 255) / 256 * 256)
@@ -27,6 +30,7 @@ static __device__ __align__(256) unsigned char scratch[NA_BYTES];
 
 #define NA_MAX_DEVICES 64
 static unsigned char* g_scratch_ptr[NA_MAX_DEVICES];      // device address of `scratch` on each GPU (0 = not resolved)
+static hipEvent_t g_scratch_done[NA_MAX_DEVICES];         // recorded behind the last kernel of the latest call on each GPU
 
 int lsr_noalloc_init(lsr_ctx* ctx) {
     if (ctx->device < 0 || ctx->device >= NA_MAX_DEVICES) return LSR_OK;      // entry point reports the missing address
@@ -35,6 +39,8 @@ int lsr_noalloc_init(lsr_ctx* ctx) {
     void* ptr = nullptr;
     LSR_HIP_CHECK(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
     if (!ptr) return lsr_fail(ctx, LSR_ERR_HIP, "hipGetSymbolAddress returned a null address for the static workspace");
+    // created here, at context creation, so that the entry point itself creates nothing
+    LSR_HIP_CHECK(ctx, hipEventCreateWithFlags(&g_scratch_done[ctx->device], hipEventDisableTiming));
     g_scratch_ptr[ctx->device] = (unsigned char*)ptr;
     return LSR_OK;
 }
@@ -77,9 +83,20 @@ extern "C" int lsr_recognize_batch_noalloc(lsr_ctx* ctx, const float* audio_d, c
     ws.frame_info = base + NA_OFF_INFO;
     ws.frame_utt = (int32_t*)(base + NA_OFF_FUTT);
     ws.uttmax = (unsigned int*)(base + NA_OFF_UMAX);      // cleared by the front-end launcher on every call
-    int rc;
-    if ((rc = lsr_launch_mfcc_ws(ctx, audio_d, 0, sample_off_d, frame_off_d, n_utts, total_frames, feats, ws))) return rc;
-    if ((rc = lsr_launch_emission(ctx, feats, total_frames, ll))) return rc;
-    return lsr_launch_viterbi_loop(ctx, ll, frame_off_d, n_utts, total_frames, max_frames, scores_d, paths_d, labels_d,
-                                   n_labels_d, label_cap, tracer);
+    // the previous user of the array on this GPU (any stream) must have finished before this call's kernels start
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &capture) != hipSuccess) capture = hipStreamCaptureStatusNone;
+    const bool ordered = capture == hipStreamCaptureStatusNone;
+    if (ordered) LSR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, g_scratch_done[ctx->device], 0));
+    int rc = lsr_launch_mfcc_ws(ctx, audio_d, 0, sample_off_d, frame_off_d, n_utts, total_frames, feats, ws);
+    if (rc == LSR_OK) rc = lsr_launch_emission(ctx, feats, total_frames, ll);
+    if (rc == LSR_OK)
+        rc = lsr_launch_viterbi_loop(ctx, ll, frame_off_d, n_utts, total_frames, max_frames, scores_d, paths_d, labels_d,
+                                     n_labels_d, label_cap, tracer);
+    if (ordered) {
+        const hipError_t e = hipEventRecord(g_scratch_done[ctx->device], ctx->stream);      // also after a failed launch
+        if (e != hipSuccess && rc == LSR_OK)
+            rc = lsr_fail(ctx, LSR_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+    }
+    return rc;
 }

@@ -123,13 +123,19 @@ void lsr_pipeline_destroy(lsr_ctx* ctx) {
 
 static int pipe_get(lsr_ctx* ctx, int threads, lsr_pipeline** out) {
     if (!ctx->pipeline) {
-        lsr_pipeline* p = new lsr_pipeline();
-        ctx->pipeline = p;
-        LSR_HIP_CHECK(ctx, hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
-        LSR_HIP_CHECK(ctx, hipEventCreateWithFlags(&p->fence, hipEventDisableTiming));
+        // the context only sees a pipeline whose stream and events all exist; a creation that fails half way is
+        // taken apart again (lsr_pipeline_destroy skips what was never created)
+        ctx->pipeline = new lsr_pipeline();
+        lsr_pipeline* p = ctx->pipeline;
+        hipError_t e = hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->fence, hipEventDisableTiming);
         for (auto& s : p->slot) {
-            LSR_HIP_CHECK(ctx, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
-            LSR_HIP_CHECK(ctx, hipEventCreateWithFlags(&s.decoded, hipEventDisableTiming));
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.decoded, hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            lsr_pipeline_destroy(ctx);
+            return lsr_fail(ctx, LSR_ERR_HIP, "creating the upload pipeline failed: %s", hipGetErrorString(e));
         }
     }
     lsr_pipeline* p = ctx->pipeline;

@@ -15,6 +15,12 @@ agrees with it up to the log-mel stage to 1e-5 dB
 (tests/test_oracle_mfcc_crosscheck.py); that rules out a misreading of the
 algorithm, it does not pin the padding mode or librosa's own rounding points.
 
+What IS pinned is the part of the stage that the reference's own file defines: tests/golden/mfcc_g8_glue.npz
+(tools/make_golden_mfcc_glue.py) holds outputs of the reference's real MFCC.normalize_mfccs, and of its real
+MFCC.__post_init__ / MFCC.batch run with a stand-in ``librosa`` module whose four functions are the stage
+functions below - that fixes mfcc.py:39-43,84 (both deltas taken from the un-normalised statics, the order
+of the concatenation, the transposition) and mfcc.py:50-69, and nothing of librosa's arithmetic.
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import it.
 """
 from __future__ import annotations
@@ -119,6 +125,11 @@ def delta(c: np.ndarray, order: int) -> np.ndarray:
     return scipy.signal.savgol_filter(c, DELTA_WIDTH, deriv=order, axis=-1, mode="interp", polyorder=order)
 
 
+def dct_mfcc(log_mel: np.ndarray, n_mfcc: int = N_MFCC) -> np.ndarray:
+    """librosa.feature.mfcc(S=log_mel, n_mfcc=n): orthonormal DCT-II over the mel axis, first n rows."""
+    return scipy.fftpack.dct(log_mel, axis=-2, type=2, norm="ortho")[:n_mfcc, :]
+
+
 def normalize_statics(c: np.ndarray) -> np.ndarray:
     """mfcc.py:50-69: axis=0 on a (13, T) array, i.e. per FRAME across coefficients."""
     mean = np.mean(c, axis=0, keepdims=True)
@@ -133,7 +144,7 @@ def mfcc_features(y: np.ndarray, sr: float = 16000, n_mfcc: int = N_MFCC) -> np.
     if y.ndim != 1:
         raise ValueError("Input signal must be 1-dimensional.")
     log_mel = power_to_db(mel_power(y, sr))
-    c = scipy.fftpack.dct(log_mel, axis=-2, type=2, norm="ortho")[:n_mfcc, :]
+    c = dct_mfcc(log_mel, n_mfcc)
     d1 = delta(c, 1)
     d2 = delta(c, 2)
     return np.concatenate((normalize_statics(c), d1, d2), axis=0)

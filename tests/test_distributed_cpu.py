@@ -54,6 +54,52 @@ def _m_step(stats, n):
     return m._means, m._covariances, m._transition_probs.to_array()
 
 
+def _word_stats(seed, sizes=(5, 3, 4)):
+    """Reduced statistics (count, sum_x, sum_xx, transition counts) of a few word models from random frames."""
+    rng = np.random.default_rng(seed)
+    n = sum(sizes)
+    count = rng.integers(60, 200, size=n).astype(np.float64)
+    sum_x = np.zeros((n, 39))
+    sum_xx = np.zeros((n, 39, 39))
+    for s in range(n):
+        x = (rng.standard_normal((int(count[s]), 39)) * rng.uniform(0.5, 3, size=39) + rng.uniform(-2, 2, size=39)).astype(np.float32)
+        x = x.astype(np.float64)
+        sum_x[s] = x.sum(axis=0)
+        sum_xx[s] = x.T @ x
+    trans = np.zeros((n, n))
+    lo = 0
+    for k in sizes:
+        for i in range(k):
+            trans[lo + i, lo + i] = rng.integers(5, 50)
+            if i + 1 < k:
+                trans[lo + i, lo + i + 1] = rng.integers(1, 9)
+        lo += k
+    return sizes, count, sum_x, sum_xx, trans
+
+
+def _continuous_trainer(sizes):
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainable, HiddenMarkovModelTrainContinuous, TransitionProbabilities
+
+    tc = HiddenMarkovModelTrainContinuous(isTqdm=False)
+    for label, k in zip("ABC", sizes):
+        m = HiddenMarkovModelTrainable(label, isTqdm=False)
+        m._means = np.zeros((k, 39), np.float32)
+        m._covariances = m._init_covariance(39, k)
+        m._transition_probs = TransitionProbabilities.from_num_of_states(k)
+        m._update_inference_weights()
+        tc.add_model(m)
+    return tc
+
+
+def _m_steps_of_trainer(tc, stats):
+    sizes, count, sum_x, sum_xx, trans = stats
+    base, _ = tc._layout()
+    tc._m_steps(base, count, sum_x, sum_xx, trans)
+    g = [g for lab in tc._models_loaded for g in tc._trainable_models[lab]._multivariate_normals]
+    return (np.stack([x.whiten for x in g]), np.array([x.log_pdet for x in g]), np.stack([x.tri for x in g]),
+            np.stack([x.mean for x in g]))
+
+
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -82,7 +128,17 @@ def _worker(rank, world, port, out_dir):
         part[-25:] += np.bincount([state[lo - 1] * 5 + state[lo]], minlength=25)
     total = D.all_reduce_stats(torch.from_numpy(part)).numpy()
     means, cov, trans = _m_step(total, 5)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), means=means, cov=cov, trans=trans, total=total)
+    # M-step of a continuous trainer with the per-state factorisation dealt out over the ranks (rank r factors
+    # states r, r + 2, ...; one all-gather) and, for comparison, with every rank factoring every state
+    stats = _word_stats(11)
+    tc = _continuous_trainer(stats[0])
+    assert tc.shard_factorization
+    sharded = _m_steps_of_trainer(tc, stats)
+    tc2 = _continuous_trainer(stats[0])
+    tc2.shard_factorization = False
+    full = _m_steps_of_trainer(tc2, stats)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), means=means, cov=cov, trans=trans, total=total,
+             **{f"sharded{i}": a for i, a in enumerate(sharded)}, **{f"full{i}": a for i, a in enumerate(full)})
     dist.destroy_process_group()
 
 
@@ -93,6 +149,21 @@ def test_two_rank_gather_and_allreduce(tmp_path):
     r1 = np.load(tmp_path / "rank1.npz")
     for k in ("means", "cov", "trans", "total"):
         assert np.array_equal(r0[k], r1[k], equal_nan=True), k          # every rank holds the same model
+    # the dealt-out factorisation gives every rank the bits of the serial path (SciPy's eigendecomposition state by state)
+    from loe_speech_recognition_amd import MultivariateNormal
+
+    stats = _word_stats(11)
+    tc = _continuous_trainer(stats[0])
+    here = _m_steps_of_trainer(tc, stats)
+    covs = np.concatenate([tc._trainable_models[lab]._covariances for lab in tc._models_loaded])
+    mus = np.concatenate([tc._trainable_models[lab]._means for lab in tc._models_loaded])
+    serial = [MultivariateNormal.from_means_covariances(m, c) for m, c in zip(mus, covs)]
+    for i in range(4):
+        for r in (r0, r1):
+            assert np.array_equal(r[f"sharded{i}"], here[i]) and np.array_equal(r[f"full{i}"], here[i]), i
+    assert np.array_equal(here[0], np.stack([g.whiten for g in serial]))
+    assert np.array_equal(here[1], np.array([g.log_pdet for g in serial]))
+    assert np.array_equal(here[2], np.tril(np.swapaxes(np.linalg.qr(np.swapaxes(here[0], 1, 2), mode="r"), 1, 2)))
     frames, state = _aligned_data()
     single = _partial_stats(frames, state, 5)
     assert np.allclose(r0["total"], single, rtol=1e-12, atol=1e-9)

@@ -27,9 +27,10 @@ def test_device_pack_unpack_equal_host_layout(n_total, world):
     for r in range(world):
         lo, hi = D.shard_bounds(n_total, r, world)
         piece = gathered[r]
-        # a rank without utterances still contributes a full piece of padding records
-        src_l = d_lab[lo:hi].contiguous() if hi > lo else d_lab[:1]
-        src_n = d_n[lo:hi].contiguous() if hi > lo else d_n[:1]
+        # a rank without utterances (n_total < world) still contributes a full piece of padding records; its
+        # empty tensors have a null data pointer, which the entry point accepts for an empty shard
+        src_l, src_n = d_lab[lo:hi].contiguous(), d_n[lo:hi].contiguous()
+        assert hi > lo or src_l.data_ptr() == 0
         eng._check(eng.lib.lsr_pack_label_records(eng.ctx, eng._ptr(src_l), eng._ptr(src_n), hi - lo, cap, shard_cap,
                                                   eng._ptr(piece)))
         eng.synchronize()
@@ -57,6 +58,9 @@ def test_one_rank_communicator_gather_and_reduce():
         comm.all_reduce_stats(d)
         eng.synchronize()
         assert np.array_equal(d.cpu().numpy(), stats)
+        # null pointers are only refused for a shard that has utterances
+        rc = eng.lib.lsr_pack_label_records(eng.ctx, None, None, 3, 16, 8, eng._ptr(g_lab))
+        assert rc == -1
         with pytest.raises(_native.NativeError):          # the shard size must match the communicator's rank
             comm.gather_label_records(eng.to_device(lab[:5]), eng.to_device(n[:5]), 257)
     finally:

@@ -104,3 +104,25 @@ def test_int16_pcm_ingestion_matches_float_path():
     assert inf.recognize_audio(pcm) == inf.recognize_audio(as_float) == truth
     with pytest.raises(TypeError):
         MFCC.batch_int16(as_float)
+
+
+def test_g8_reference_glue_fixture():
+    """tests/golden/mfcc_g8_glue.npz: outputs of the reference's real MFCC.__post_init__ / MFCC.batch (run over
+    a stand-in librosa whose stages are the oracle's) and of its real normalize_mfccs.  The device must
+    reproduce the layout mfcc.py:39-43,84 defines - normalised statics, then the deltas of the UN-normalised
+    statics, transposed by batch - within the 1e-4 tolerance; librosa's arithmetic itself stays unpinned."""
+    import os
+
+    from loe_speech_recognition_amd import MFCC
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mfcc_g8_glue.npz"), allow_pickle=False)
+    sigs = [g[f"sig{i}"] for i in range(int(g["n_signals"]))]
+    got = MFCC.batch(sigs, 16000)
+    for i, s in enumerate(sigs):
+        assert got[i].shape == g[f"batch{i}"].shape and got[i].dtype == np.float32
+        assert rel_err(got[i], g[f"batch{i}"]) <= 1e-4, i
+        single = MFCC(s, 16000).feature_vector
+        assert single.shape == g[f"feat{i}"].shape and rel_err(single, g[f"feat{i}"]) <= 1e-4, i
+        # the statics block is what the reference's own normalize_mfccs makes of the un-normalised cepstra
+        c = M.dct_mfcc(M.power_to_db(M.mel_power(s)))
+        assert rel_err(single[:13], M.normalize_statics(c)) <= 1e-4, i

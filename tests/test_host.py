@@ -176,3 +176,50 @@ def test_records_to_strings_vectorised_path_equals_the_loop():
     want = ["".join(long_names[w] for w in lab[i, :max(0, min(int(cnt[i]), 16))]) for i in range(500)]
     assert _native.records_to_strings(lab, cnt, long_names) == want
     assert _native.records_to_strings(np.zeros((0, 4), np.uint8), np.zeros(0, np.int32), names) == []
+
+
+def test_batched_factorisation_carries_the_bits_of_the_serial_path():
+    """factor_covariances (threads inside the helper extension, SciPy's own dsyevr / dgeqrf) against
+    MultivariateNormal.from_means_covariances state by state and numpy.linalg.qr: same eigen-whitening, log
+    determinant and triangular factor to the bit, for any thread count and for a dealt-out subset; same
+    exceptions for matrices SciPy refuses."""
+    import numpy as np
+    import pytest
+
+    from loe_speech_recognition_amd import MultivariateNormal
+    from loe_speech_recognition_amd.hidden_markov_model import factor_covariances
+    from loe_speech_recognition_amd import _lsr_pyhelper as H
+    import scipy.linalg.cython_lapack as lapack
+
+    rng = np.random.default_rng(21)
+    S, d = 23, 39
+    a = rng.standard_normal((S, d, d)) * rng.uniform(0.1, 30, size=(S, 1, 1))
+    cov = (a @ a.transpose(0, 2, 1) / d + 1e-3 * np.eye(d)).astype(np.float32)
+    cov[5] = np.eye(d, dtype=np.float32) * 0.01                      # the trainers' initial covariance
+    mu = rng.standard_normal((S, d)).astype(np.float32)
+    serial = [MultivariateNormal.from_means_covariances(m, c) for m, c in zip(mu, cov)]
+    tri = np.tril(np.swapaxes(np.linalg.qr(np.swapaxes(np.stack([g.whiten for g in serial]), 1, 2), mode="r"), 1, 2))
+    for threads in (1, 3, 16):
+        got = factor_covariances(mu, cov, threads=threads)
+        for s in range(S):
+            assert np.array_equal(got[s].whiten, serial[s].whiten) and got[s].log_pdet == serial[s].log_pdet, (threads, s)
+            assert np.array_equal(got[s].mean, serial[s].mean) and np.array_equal(got[s].tri, tri[s]), (threads, s)
+    # a dealt-out share touches only its own rows
+    lam, U, L, st = np.zeros((S, d)), np.zeros((S, d, d)), np.zeros((S, d, d)), np.full(S, 9, np.int32)
+    caps = lapack.__pyx_capi__
+    H.factor_batch(caps["dsyevr"], caps["dgeqrf"], np.ascontiguousarray(cov, dtype=np.float64), lam, U, L, st, S, d, 2, 3, 4)
+    assert np.array_equal(U[2::3], np.stack([g.whiten for g in serial])[2::3]) and (st[2::3] == 0).all()
+    mask = np.ones(S, bool)
+    mask[2::3] = False
+    assert (U[mask] == 0).all() and (st[mask] == 9).all()
+    # matrices SciPy refuses: the first failing state decides, with SciPy's exception types
+    bad = cov.copy()
+    bad[7] = 0
+    with pytest.raises(np.linalg.LinAlgError):
+        factor_covariances(mu, bad)
+    bad[4] = -np.eye(d, dtype=np.float32)
+    with pytest.raises(ValueError, match="positive semidefinite"):
+        factor_covariances(mu, bad)
+    bad[1, 0, 0] = np.nan
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        factor_covariances(mu, bad)

@@ -111,3 +111,45 @@ def test_input_validation():
         M.mfcc_features([0.0] * 2000)
     with pytest.raises(ValueError):
         M.mfcc_features(np.zeros((2, 2000), np.float32))
+
+
+# ---- what the reference's own mfcc.py defines, against outputs of the reference itself -----------------------
+# tests/golden/mfcc_g8_glue.npz (tools/make_golden_mfcc_glue.py): the real MFCC.normalize_mfccs, and the real
+# MFCC.__post_init__ / MFCC.batch run over a stand-in librosa whose stages are this oracle's.  Pins mfcc.py:39-43,
+# 50-69, 84 - NOT librosa's arithmetic.
+def _glue():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mfcc_g8_glue.npz"), allow_pickle=False)
+
+
+def test_g8_normalize_mfccs_equals_the_reference():
+    g = _glue()
+    for i in range(5):
+        got = M.normalize_statics(g[f"norm{i}_in"])
+        assert got.dtype == g[f"norm{i}_out"].dtype
+        assert np.array_equal(got, g[f"norm{i}_out"]), i
+    # the normalisation runs across the 13 coefficients of one frame, not along time
+    x = g["norm2_in"]
+    assert np.allclose(g["norm2_out"].mean(axis=0), 0, atol=1e-5) and not np.allclose(g["norm2_out"].mean(axis=1), 0, atol=1e-2)
+    assert np.array_equal(g["norm4_out"], np.zeros_like(x[:, :10]))            # zero variance: (x - mean) / 1e-8 = 0
+
+
+def test_g8_feature_layout_equals_the_reference():
+    import json
+
+    g = _glue()
+    calls = json.loads(str(g["calls_of_first_clip"]))
+    assert [c[0] for c in calls] == ["melspectrogram", "power_to_db", "mfcc", "delta", "delta"]
+    assert calls[3][1] == {"order": 1, "input_is_the_unnormalised_mfcc_output": True}
+    assert calls[4][1] == {"order": 2, "input_is_the_unnormalised_mfcc_output": True}
+    sigs = [g[f"sig{i}"] for i in range(int(g["n_signals"]))]
+    batch = M.mfcc_batch(sigs, 16000)
+    for i, s in enumerate(sigs):
+        f = M.mfcc_features(s)
+        assert f.dtype == g[f"feat{i}"].dtype and np.array_equal(f, g[f"feat{i}"]), i
+        assert np.array_equal(batch[i], g[f"batch{i}"]) and batch[i].shape == (1 + s.shape[0] // 160, 39), i
+        # rows 0..12 normalised statics, 13..25 delta, 26..38 delta-delta of the UN-normalised statics
+        c = M.dct_mfcc(M.power_to_db(M.mel_power(s)))
+        assert np.array_equal(g[f"feat{i}"][13:26], M.delta(c, 1)) and np.array_equal(g[f"feat{i}"][26:], M.delta(c, 2))
+        assert not np.allclose(g[f"feat{i}"][13:26], M.delta(M.normalize_statics(c), 1), atol=1e-3)

@@ -44,6 +44,11 @@ def test_noalloc_equals_recognize_batch_twice_second_smaller():
             o.fill_(0x5A if o.dtype != eng.torch.float32 else 1.0)
         assert _call(eng, lib.lsr_recognize_batch, ab, ref) == 0
         assert _call(eng, lib.lsr_recognize_batch_noalloc, ab, got) == 0, lib.lsr_last_error(eng.ctx)
+        # the call allocates nothing: free device memory is the same before and after (the call above was the
+        # warm-up: kernels are loaded, the outputs exist)
+        free_before = eng.torch.cuda.mem_get_info(eng.device)[0]
+        assert _call(eng, lib.lsr_recognize_batch_noalloc, ab, got) == 0, lib.lsr_last_error(eng.ctx)
+        assert eng.torch.cuda.mem_get_info(eng.device)[0] == free_before
         for r, g in zip(ref, got):
             r, g = r.cpu().numpy(), g.cpu().numpy()
             if r.ndim == 2:                      # label records: only the first n_labels entries are written
@@ -53,6 +58,45 @@ def test_noalloc_equals_recognize_batch_twice_second_smaller():
             else:
                 assert np.array_equal(r.view(np.uint8), g.view(np.uint8))
         assert (ref[3].cpu().numpy() > 0).all()
+
+
+def test_noalloc_calls_on_two_streams_are_ordered():
+    """Two calls in a row on different streams share the static workspace: the second waits for the first on the
+    device (per-GPU event), so both produce the results of lsr_recognize_batch."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, synthetic
+
+    models = synthetic.load_word_models()
+    inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
+    inf._log_transition_probability_between_words = -100
+    eng = inf._bind()
+    lib, t = eng.lib, eng.torch
+    a_sigs, _ = synthetic.batch(3, 64, 4, start=700)
+    b_sigs, _ = synthetic.batch(3, 48, 2, start=900)
+    a, b = (eng.audio_batch([np.asarray(s, dtype=np.float32) for s in sigs]) for sigs in (a_sigs, b_sigs))
+    ref_a, ref_b, got_a, got_b = (_outputs(eng, x) for x in (a, b, a, b))
+    assert _call(eng, lib.lsr_recognize_batch, a, ref_a) == 0 and _call(eng, lib.lsr_recognize_batch, b, ref_b) == 0
+    side = t.cuda.Stream(device=eng.device)
+    main = t.cuda.current_stream(eng.device)
+    t.cuda.synchronize()
+    P = ctypes.c_void_p
+
+    def submit(ab, out):
+        scores, paths, labels, n_labels = out
+        return lib.lsr_recognize_batch_noalloc(eng.ctx, P(ab.audio.data_ptr()), P(ab.sample_off.data_ptr()),
+                                               P(ab.frame_off.data_ptr()), ab.n, ab.total_frames, ab.max_frames,
+                                               P(scores.data_ptr()), P(paths.data_ptr()), P(labels.data_ptr()),
+                                               P(n_labels.data_ptr()), LABEL_CAP)
+    try:
+        assert submit(a, got_a) == 0                                   # on the context's stream, not waited for
+        eng._check(lib.lsr_set_stream(eng.ctx, P(side.cuda_stream)))
+        assert submit(b, got_b) == 0                                   # on another stream right behind it
+    finally:
+        t.cuda.synchronize()
+        eng._check(lib.lsr_set_stream(eng.ctx, P(main.cuda_stream)))
+    for ref, got in ((ref_a, got_a), (ref_b, got_b)):
+        assert np.array_equal(ref[0].cpu().numpy().view(np.uint8), got[0].cpu().numpy().view(np.uint8))
+        assert np.array_equal(ref[1].cpu().numpy(), got[1].cpu().numpy())
+        assert np.array_equal(ref[3].cpu().numpy(), got[3].cpu().numpy())
 
 
 def test_noalloc_rejects_batches_beyond_the_static_workspace():
