@@ -268,6 +268,12 @@ extern "C" int lsr_ctx_destroy(lsr_ctx* ctx) {
     free_ptr(ctx->d_wfrag);
     free_ptr(ctx->d_lognorm);
     free_ptr(ctx->d_logw);
+    for (int k = 0; k < LSR_MODEL_SLOTS; ++k)
+        if (k != ctx->cur_model) {
+            free_ptr(ctx->models[k].d_wfrag);
+            free_ptr(ctx->models[k].d_lognorm);
+            free_ptr(ctx->models[k].d_logw);
+        }
     free_ptr(ctx->d_band);
     free_ptr(ctx->d_flags);
     free_ptr(ctx->d_word_of);
@@ -356,6 +362,30 @@ extern "C" int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, 
     if ((rc = upload(ctx, &ctx->d_lognorm, log_norm, (size_t)n_states, "log normalisers"))) return rc;
     ctx->n_states = n_states;
     ctx->n_mix = 1;
+    return LSR_OK;
+}
+
+extern "C" int lsr_model_slot(lsr_ctx* ctx, int slot) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (slot < 0 || slot >= LSR_MODEL_SLOTS)
+        return lsr_fail(ctx, LSR_ERR_ARG, "lsr_model_slot: slot %d outside 0..%d", slot, LSR_MODEL_SLOTS - 1);
+    if (slot == ctx->cur_model) return LSR_OK;
+    // only pointers change hands: kernels already queued keep reading the buffers they were launched with
+    lsr_ctx::model_slot& out = ctx->models[ctx->cur_model];
+    out.n_states = ctx->n_states;
+    out.n_mix = ctx->n_mix;
+    out.whiten_triangular = ctx->whiten_triangular;
+    out.d_wfrag = ctx->d_wfrag;
+    out.d_lognorm = ctx->d_lognorm;
+    out.d_logw = ctx->d_logw;
+    const lsr_ctx::model_slot& in = ctx->models[slot];
+    ctx->n_states = in.n_states;
+    ctx->n_mix = in.n_mix;
+    ctx->whiten_triangular = in.whiten_triangular;
+    ctx->d_wfrag = in.d_wfrag;
+    ctx->d_lognorm = in.d_lognorm;
+    ctx->d_logw = in.d_logw;
+    ctx->cur_model = slot;
     return LSR_OK;
 }
 

@@ -45,6 +45,15 @@ struct lsr_ctx {
     int n_mix = 1;                   // components per state (n_states counts components)
     double* d_logw = nullptr;        // [S] log mixture weights (n_mix > 1 only)
 
+    // models kept on the device besides the current one (lsr_model_slot): the fields above belong to slot cur_model
+    struct model_slot {
+        int n_states = 0, n_mix = 1;
+        bool whiten_triangular = false;
+        double *d_wfrag = nullptr, *d_lognorm = nullptr, *d_logw = nullptr;
+    };
+    model_slot models[LSR_MODEL_SLOTS];
+    int cur_model = 0;
+
     int chain_emission_mode = 0;     // LSR_CHAIN_EMISSION_*
 
     // loop graph (device)

@@ -54,6 +54,7 @@ def _declare(lib) -> None:
         "lsr_host_dct_matrix": (None, [POINTER(c_double)]),
         "lsr_model_upload": (c_int, [P, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
         "lsr_model_set_mixtures": (c_int, [P, c_int, POINTER(c_double)]),
+        "lsr_model_slot": (c_int, [P, c_int]),
         "lsr_loop_graph_upload": (c_int, [P, c_int, c_int, POINTER(c_float), POINTER(c_int32), POINTER(c_int32), c_int]),
         "lsr_loop_set_between": (c_int, [P, c_double, c_int]),
         "lsr_mfcc_batch": (c_int, [P, P, P, P, c_int, c_int64, P]),
@@ -109,6 +110,7 @@ EXPORTED_SYMBOLS = [
     "lsr_comm_destroy", "lsr_allgather_labels", "lsr_allreduce_stats", "lsr_label_record_bytes",
     "lsr_host_pack_label_records", "lsr_host_unpack_label_records", "lsr_pack_label_records", "lsr_unpack_label_records",
     "lsr_labels_from_paths", "lsr_ll_stride", "lsr_decode_chain_batch_wide", "lsr_chain_emission_mode",
+    "lsr_model_slot",
 ]
 
 
@@ -202,6 +204,9 @@ class Engine:
         self._model_token = None
         self._graph_token = None
         self._rotated = {}               # token -> triangularised whitening matrices (at most 8 kept)
+        # models resident on the device: token -> (slot, states); slot 0 takes the uploads without a token
+        self._resident = {}
+        self._slot = 0
         self._between = None
 
     # -- helpers ----------------------------------------------------------------------------------
@@ -349,26 +354,46 @@ class Engine:
             return
         if triangular is None:
             triangular = os.environ.get("LSR_DENSE_WHITEN", "0") != "1"
+        # a model that is still resident only needs its slot selected: callers that alternate between a few models
+        # (a loop decoder and an isolated-word collection, say) switch tokens on every call
+        key = (token, triangular, n_mix)
+        hit = self._resident.get(key) if token is not None else None
+        if hit is not None:
+            self._resident[key] = self._resident.pop(key)               # most recently used last
+            self._select_slot(hit[0])
+            self._model_token = token
+            self.n_model_states = hit[1]
+            return
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         whiten = np.ascontiguousarray(whiten, dtype=np.float64)
         if triangular:
-            # callers that alternate between a few models (a loop decoder and an isolated-word collection, say)
-            # switch tokens on every call: the rotation of a token's matrices is kept, only the upload repeats
             cached = self._rotated.get(token) if token is not None else None
             if cached is None and rotated is not None:
                 cached = np.ascontiguousarray(rotated, dtype=np.float64)
                 assert cached.shape == whiten.shape
             elif cached is None:
                 cached = np.tril(np.swapaxes(np.linalg.qr(np.swapaxes(whiten, 1, 2), mode="r"), 1, 2))      # batched
-                if token is not None:
-                    if len(self._rotated) >= 8:
-                        self._rotated.pop(next(iter(self._rotated)))
-                    self._rotated[token] = cached
+            if token is not None and rotated is None:
+                if len(self._rotated) >= 8:
+                    self._rotated.pop(next(iter(self._rotated)))
+                self._rotated[token] = cached
             whiten = cached
         log_norm = np.ascontiguousarray(log_norm, dtype=np.float64)
         S = mean.shape[0]
         assert mean.shape == (S, DIM) and whiten.shape == (S, DIM, DIM) and log_norm.shape == (S,)
+        if token is None:
+            slot = 0
+        else:
+            used = {v[0] for v in self._resident.values()}
+            free = [k for k in range(1, self.MODEL_SLOTS) if k not in used]
+            if free:
+                slot = free[0]
+            else:                                                       # evict the least recently used
+                oldest = next(iter(self._resident))
+                slot = self._resident.pop(oldest)[0]
+        self._select_slot(slot)
         dp = POINTER(c_double)
+        self._model_token = None
         self._check(self.lib.lsr_model_upload(self.ctx, S, mean.ctypes.data_as(dp), whiten.ctypes.data_as(dp),
                                               log_norm.ctypes.data_as(dp)))
         if n_mix > 1:
@@ -377,6 +402,15 @@ class Engine:
             self._check(self.lib.lsr_model_set_mixtures(self.ctx, n_mix, lw.ctypes.data_as(dp)))
         self._model_token = token
         self.n_model_states = S // n_mix
+        if token is not None:
+            self._resident[key] = (slot, self.n_model_states)
+
+    MODEL_SLOTS = 8                      # LSR_MODEL_SLOTS
+
+    def _select_slot(self, slot: int) -> None:
+        if slot != self._slot:
+            self._check(self.lib.lsr_model_slot(self.ctx, slot))
+            self._slot = slot
 
     def set_loop_graph(self, token, band: np.ndarray, lower: Sequence[int], upper: Sequence[int], silence_word: int) -> None:
         if token is not None and token == self._graph_token:
@@ -559,25 +593,56 @@ class Engine:
         return scores, paths, final
 
     def decode_chain_device(self, fb: FeatureBatch, d_off, total_chain: int, d_state, d_band, d_start, wide: bool = False,
-                            want_paths: bool = True):
+                            want_paths: bool = True, want_final: bool = False):
         """decode_chain for a chain description that already lives on the device (int64 offsets [B + 1], int32
         model state, float32 band [3, total_chain], uint8 start flags per chain position), as a trainer keeps it
-        between iterations: no host validation, no upload.  Returns (scores, paths)."""
+        between iterations: no host validation, no upload.  Returns (scores, paths), or (scores, paths, final)
+        with ``want_final`` (last-frame scores of every chain position, chains of at most 64 states)."""
         t = self.torch
         assert d_off.dtype == t.int64 and d_state.dtype == t.int32 and d_band.dtype == t.float32 and d_start.dtype == t.uint8
         assert d_off.shape == (fb.n + 1,) and d_state.shape == (total_chain,) and d_band.shape == (3, total_chain)
         assert d_start.shape == (total_chain,) and d_band.is_contiguous()
+        assert not (wide and want_final)
         scores = self.empty((fb.n,), t.float32)
         paths = self.empty((fb.total_frames,), t.int8) if want_paths else None
+        final = self.empty((fb.n, 64), t.float32) if want_final else None
         fn = self.lib.lsr_decode_chain_batch_wide if wide else self.lib.lsr_decode_chain_batch
         args = [self.ctx, self._ptr(fb.feats), self._ptr(fb.frame_off), fb.n, fb.total_frames, fb.max_frames, self._ptr(d_off),
                 total_chain, self._ptr(d_state), self._ptr(d_band), self._ptr(d_start), self._ptr(scores), self._ptr(paths)]
         if not wide:
-            args.append(c_void_p(0))
+            args.append(self._ptr(final))
         self._check(fn(*args))
         self.last_chain = (d_off, d_state)
         self._chain_keepalive = (d_off, d_state, d_band, d_start)
-        return scores, paths
+        return (scores, paths, final) if want_final else (scores, paths)
+
+    def uniform_chains(self, key, n_utts: int, ids: np.ndarray, band: np.ndarray, start: np.ndarray):
+        """Device description of ``n_utts`` copies of ONE chain (every utterance is decoded against the same
+        states: an isolated word model, or a collection of them side by side): (offsets, total, states, band,
+        start flags) for decode_chain_device.  Kept per (key, n_utts) - the key names the model the arrays were
+        made from - so that a caller decoding batch after batch builds and uploads them once."""
+        cache = self.__dict__.setdefault("_uniform_chains", {})
+        hit = cache.get((key, n_utts))
+        if hit is not None:
+            cache[(key, n_utts)] = cache.pop((key, n_utts))
+            return hit
+        n = int(ids.shape[0])
+        if not 1 <= n <= MAX_STATES:
+            raise ValueError(f"every chain needs 1..{MAX_STATES} states")
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        band = np.ascontiguousarray(band, dtype=np.float32)
+        if ids.min() < 0 or ids.max() >= self.n_model_states:
+            raise ValueError("chain_state out of range of the uploaded model")
+        if band.shape != (3, n) or np.isnan(band).any():
+            raise ValueError("NaN transition log-probability" if band.shape == (3, n) else "band must be [3, states]")
+        t = self.torch
+        d_off = t.arange(n_utts + 1, dtype=t.int64, device=self.device) * n
+        out = (d_off, n * n_utts, self.to_device(ids).repeat(n_utts), self.to_device(band).repeat(1, n_utts).contiguous(),
+               self.to_device(np.ascontiguousarray(start, dtype=np.uint8)).repeat(n_utts))
+        if len(cache) >= 8:
+            cache.pop(next(iter(cache)))
+        cache[(key, n_utts)] = out
+        return out
 
     def remux_slots(self, paths, fb: "FeatureBatch", chain_off, chain_state, chain_word, n_states: int,
                     drop_last_run: bool):

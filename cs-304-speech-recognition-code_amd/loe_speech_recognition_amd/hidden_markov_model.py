@@ -276,10 +276,9 @@ class HiddenMarkovModel:
         token, arrays = self._device_model()
         eng.set_model(token, *arrays)
         ids, band, start = self._chain()
-        n = ids.shape[0]
-        off = np.arange(fb.n + 1, dtype=np.int64) * n
-        scores, paths, _ = eng.decode_chain(fb, off, np.tile(ids, fb.n), np.tile(band, (1, fb.n)),
-                                            np.tile(start, fb.n), want_paths=want_paths)
+        d_off, total, d_ids, d_band, d_start = eng.uniform_chains((token, band.tobytes()), fb.n, ids, band, start)
+        scores, paths = eng.decode_chain_device(fb, d_off, total, d_ids, d_band, d_start, wide=ids.shape[0] > _native.NARROW_STATES,
+                                                want_paths=want_paths)
         scores = scores.cpu().numpy()
         plist = _native.split_ragged(paths.cpu().numpy(), fb.host_off) if want_paths else [None] * fb.n
         return [(scores[i], plist[i]) for i in range(fb.n)]
@@ -400,8 +399,8 @@ class HiddenMarkovModelTrainable(HiddenMarkovModel):
         eng.set_model(token, *arrays)
         ids, band, start = self._chain()
         n = ids.shape[0]
-        off = np.arange(fb.n + 1, dtype=np.int64) * n
-        _, paths, _ = eng.decode_chain(fb, off, np.tile(ids, fb.n), np.tile(band, (1, fb.n)), np.tile(start, fb.n))
+        d_off, total, d_ids, d_band, d_start = eng.uniform_chains((token, band.tobytes()), fb.n, ids, band, start)
+        _, paths = eng.decode_chain_device(fb, d_off, total, d_ids, d_band, d_start, wide=n > _native.NARROW_STATES)
         # a left-to-right path never decreases, so every frame feeds the state it is aligned to
         # (signal.py:23-47) and consecutive frames of an utterance count as one transition (signal.py:80-91)
         d_off, d_ids = eng.last_chain

@@ -51,15 +51,21 @@ class ModelCollection:
         eng.set_model(cache["token"], *cache["model"])
         return eng, cache
 
-    def scores_batch(self, signals) -> np.ndarray:
-        """float32 [B, n_models]: each model's Viterbi score (hidden_markov_model.py:160-198)."""
+    def scores_device(self, signals):
+        """Device tensor float32 [B, n_models]: each model's Viterbi score, left on the device."""
         eng, c = self._bind()
         fb = signals if isinstance(signals, _native.FeatureBatch) else eng.feature_batch(signals)
         n = c["start"].shape[0]
-        off = np.arange(fb.n + 1, dtype=np.int64) * n
-        _, _, final = eng.decode_chain(fb, off, np.tile(np.arange(n, dtype=np.int32), fb.n), np.tile(c["band"], (1, fb.n)),
-                                       np.tile(c["start"], fb.n), want_paths=False, want_final=True)
-        return final.cpu().numpy()[:, c["last"]]
+        d_off, total, d_ids, d_band, d_start = eng.uniform_chains(c["token"], fb.n, np.arange(n, dtype=np.int32), c["band"],
+                                                                  c["start"])
+        _, _, final = eng.decode_chain_device(fb, d_off, total, d_ids, d_band, d_start, want_paths=False, want_final=True)
+        if "d_last" not in c:
+            c["d_last"] = eng.to_device(np.asarray(c["last"], dtype=np.int64))
+        return final[:, c["d_last"]]
+
+    def scores_batch(self, signals) -> np.ndarray:
+        """float32 [B, n_models]: each model's Viterbi score (hidden_markov_model.py:160-198)."""
+        return self.scores_device(signals).cpu().numpy()
 
     def predict_batch(self, signals) -> List[str]:
         scores = self.scores_batch(signals)

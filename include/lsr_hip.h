@@ -93,6 +93,16 @@ void lsr_host_dct_matrix(double* out13x40);           /* DCT-II, orthonormal, fi
 int lsr_model_upload(lsr_ctx* ctx, int n_states, const double* mean, const double* whiten,
                      const double* log_norm);
 
+/* Several models resident at once.  A caller that alternates between a few model sets - the loop decoder's
+ * stacked words and the isolated-word collection of scripts/project3_predict_simple.py, say, or the models of
+ * successive penalties - selects a slot instead of uploading again: lsr_model_upload and lsr_model_set_mixtures
+ * write the CURRENT slot, every compute entry point reads it, lsr_model_slot makes another of the
+ * LSR_MODEL_SLOTS slots current (slot 0 at context creation; a slot that was never uploaded holds no model:
+ * LSR_ERR_STATE from the compute entry points).  Has no counterpart in the reference, whose objects each hold
+ * their own SciPy distributions (hidden_markov_model.py:283-292). */
+#define LSR_MODEL_SLOTS 8
+int lsr_model_slot(lsr_ctx* ctx, int slot);
+
 /* Gaussian-mixture emissions: regroup the uploaded Gaussians as n_states / n_mix states of n_mix
  * consecutive components with log_weights[n_states] (host, float64).  Emission scores become
  * float32(logaddexp over the components of log w + log N), accumulated sequentially in float64
