@@ -87,3 +87,49 @@ def test_flows_without_silence_model(tmp_path):
     rows = decoder.predict_sweep(mfccs, [-250])
     decoder._log_transition_probability_between_words = -250
     assert rows[0] == decoder.predict_batch(mfccs)
+
+
+def test_file_based_project4_and_project6_flows(tmp_path):
+    """scripts/project4_2digits.py, project4_phone.py (concatenated one-digit clips -> MFCC -> isolated classifier) and
+    the wav half of project6_interactive.py, each compared with the oracle's isolated classifier / loop decoder run
+    on the device's features of the same clips."""
+    import scipy.io.wavfile
+
+    from loe_speech_recognition_amd import MFCC, TIDigits, synthetic
+    from oracle import hmm_oracle as O
+
+    corpus = load("make_synthetic_corpus").write_corpus(str(tmp_path / "corpus"), isolated_per_word=4, strings_per_length=3)
+    models = str(tmp_path / "cache" / "packaged")
+    for model in synthetic.load_word_models().values():
+        model.save(models)
+    arrays = synthetic.load_word_arrays()
+    iso = [O.WordModelRef(lab, *arrays[lab]) for lab in synthetic.WORDS]
+    train = TIDigits(corpus, isLazyLoading=True).train_dataset
+    for name, n_digits, n_samples in (("project4_2digits", 2, 10), ("project4_phone", 4, 50)):
+        truth, pred = load(name).main(corpus, models)
+        assert len(truth) == len(pred) == n_samples and all(len(t) == n_digits for t in truth)
+        assert all(p in synthetic.WORDS for p in pred)                  # one label for the whole concatenation
+        feats = MFCC.batch([train.get_combined(t, key=2) for t in truth], 16000)
+        assert pred == [O.classify_isolated(iso, x) for x in feats], name
+    # the same random draw on every run with the same seed, another one with another seed
+    assert load("project4_2digits").main(corpus, models)[0] != load("project4_2digits").main(corpus, models, seed=5)[0]
+
+    # project6_interactive on recordings from the corpus: equal to the oracle's loop decode of the device features
+    words = [O.WordModelRef(lab, *arrays[lab]) for lab in synthetic.LOOP_ORDER]
+    ltp, gauss, bounds = O.stack_models(words)
+    mu, U, ld = O.export_gaussians(gauss)
+    band = O.band_from_ltp(ltp, bounds.num_states, [bounds.find_lower(s) for s in range(bounds.num_states)])
+    interactive = load("project6_interactive")
+    wavs = []
+    for dirpath, _, files in os.walk(corpus):
+        wavs += [os.path.join(dirpath, f) for f in files if len(f.split(".")[0]) == 5 and "TEST" in dirpath]   # 4 digits + take
+    assert len(wavs) >= 3
+    right = 0
+    for path in sorted(wavs)[:3]:
+        got = interactive.main(path, models)
+        sr, pcm = scipy.io.wavfile.read(path)
+        x = MFCC(pcm.astype(np.float32), sr).feature_vector.T
+        _, p = O.viterbi_loop_fast(O.emission_fast(x, mu, U, ld), band, bounds.lower, bounds.upper, -100)
+        assert got == "".join(bounds.get_labels(p)), path
+        right += got == os.path.basename(path)[:4]
+    assert right >= 2
