@@ -132,9 +132,57 @@ __device__ __forceinline__ double em_fold(double (&ss)[4], double log_norm) {
     return -0.5 * (log_norm + maha);
 }
 
-// B-operand source of a tile: x~[frame 16q + col][k = 4ks + grp]; frames beyond the batch are zero
-__device__ __forceinline__ void em_load_frames(double (&x)[4][LSR_KSTEPS], const float* __restrict__ feats, int64_t f0,
-                                               int64_t total_frames, int col, int grp) {
+// B-operand source of a tile: x~[frame 16q + col][k = 4ks + grp]; frames beyond the batch are zero.
+// The 64 feature rows of a tile are one contiguous span of 64 * 39 floats: the wavefront copies it to its LDS
+// area with ten coalesced 16-byte loads per lane (the rows start on 4-byte boundaries only, which global loads
+// accept) and every lane then picks its forty values from there - a lane reading its own values straight from
+// memory touches sixteen different rows per load instruction.  `stage` is the wavefront's LDS area
+// (EM_LDS_FLOATS floats), free between two runs.  The last tile of the batch, whose span would run past the
+// features, reads memory directly.
+#define EM_LDS_FLOATS 2560          // >= 64 * 39 staged features, >= 64 * EM_RUN scores
+typedef float em_f4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ void em_load_frames(double (&x)[4][LSR_KSTEPS], float* __restrict__ stage,
+                                               const float* __restrict__ feats, int64_t f0, int64_t total_frames,
+                                               int lane, int col, int grp) {
+    if (f0 + 64 <= total_frames) {
+        const float* src = feats + f0 * LSR_DIM;
+        // groups of four loads off one wave-uniform base: the lane's offset is one register, the rest immediates
+        // (the lane index goes through an opaque move so that the addresses are formed here, once per tile, instead
+        // of being kept in registers across the matrix loop, where there are none to spare)
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const float* lane_src = src + l * 4;
+        float* lane_dst = stage + l * 4;
+#pragma unroll
+        for (int g = 0; g < 10; g += 4) {
+            em_f4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (g + i < 9 || (g + i == 9 && l < (64 * LSR_DIM - 9 * 256) / 4)) v[i] = *(const em_f4*)(lane_src + (g + i) * 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (g + i < 9 || (g + i == 9 && l < (64 * LSR_DIM - 9 * 256) / 4))
+                    *(float4*)(lane_dst + (g + i) * 256) = float4{v[i][0], v[i][1], v[i][2], v[i][3]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* row = stage + (16 * q + col) * LSR_DIM;
+#pragma unroll
+            for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
+                const int k = 4 * ks + grp;
+                x[q][ks] = k < LSR_DIM ? (double)row[k] : 1.0;                  // feature 39 is the constant
+            }
+        }
+        // the area is written again (scores) only after every lane has read its values
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t f = f0 + 16 * q + col;
@@ -143,7 +191,7 @@ __device__ __forceinline__ void em_load_frames(double (&x)[4][LSR_KSTEPS], const
 #pragma unroll
         for (int ks = 0; ks < LSR_KSTEPS; ++ks) {
             const int k = 4 * ks + grp;
-            x[q][ks] = k < LSR_DIM ? (live ? (double)row[k] : 0.0) : 1.0;      // feature 39 is the constant
+            x[q][ks] = k < LSR_DIM ? (live ? (double)row[k] : 0.0) : 1.0;
         }
     }
 }
@@ -153,11 +201,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
     const float* __restrict__ feats, int64_t total_frames, const double* __restrict__ wfrag,
     const double* __restrict__ lognorm, const double* __restrict__ logw,
     int n_states, int n_mix, float* __restrict__ ll, int ll_stride) {
-    // [frame][(state - first state of the run) ^ frame]: the XOR keeps the per-row reads on distinct LDS
-    // banks without padding; 8 KiB per wavefront, so three workgroups fit a compute unit
-    __shared__ float tile[EM_WAVES][64][EM_RUN];
+    // per wavefront: scores [frame][(state - first state of the run) ^ frame] - the XOR keeps the per-row reads on
+    // distinct LDS banks without padding - and, between runs, the staged features of the next tile; 10 KiB per
+    // wavefront, so three workgroups fit a compute unit
+    __shared__ __attribute__((aligned(16))) float lds[EM_WAVES][EM_LDS_FLOATS];
     // readfirstlane: the wavefront index (and everything derived from it) lives in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float (*tile)[EM_RUN] = (float (*)[EM_RUN])lds[wave];
     const int col = lane & 15, grp = lane >> 4;
     const int n_cols = n_states / n_mix;                       // states = columns of the score matrix
     const int64_t n_tiles = (total_frames + 63) / 64;
@@ -179,7 +229,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
 
         if (t != loaded) {
             loaded = t;
-            em_load_frames(x, feats, f0, total_frames, col, grp);
+            em_load_frames(x, lds[wave], feats, f0, total_frames, lane, col, grp);
         }
 
         constexpr int SLOTS = em_ring<TRI>::SLOTS, RING = em_ring<TRI>::RING;
@@ -201,7 +251,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
             em_gaussian<TRI, false>(w, x, cur, cur, ss);
             const double lp = em_fold(ss, lognorm[s]);
             if (!MIX) {
-                tile[wave][lane][((s - s_begin) ^ lane) & (EM_RUN - 1)] = (float)lp;
+                tile[lane][((s - s_begin) ^ lane) & (EM_RUN - 1)] = (float)lp;
             } else {
                 const double v = logw[s] + lp;
                 if (mix == 0) {
@@ -214,7 +264,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
                 }
                 if (++mix == n_mix) {
                     const int c = s / n_mix;
-                    tile[wave][lane][((c - c0) ^ lane) & (EM_RUN - 1)] = (float)run;
+                    tile[lane][((c - c0) ^ lane) & (EM_RUN - 1)] = (float)run;
                     mix = 0;
                 }
             }
@@ -228,7 +278,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, MIX ? 2 : 3) void lsr_emission_kerne
         if (lane < c1 - c0) {
 #pragma unroll 8
             for (int r = 0; r < 64; ++r)
-                ll[(f0 + r) * ll_stride + c0 + lane] = tile[wave][r][(lane ^ r) & (EM_RUN - 1)];
+                ll[(f0 + r) * ll_stride + c0 + lane] = tile[r][(lane ^ r) & (EM_RUN - 1)];
         }
         if (c1 == n_cols && n_cols + lane < ll_stride) {
 #pragma unroll 8
@@ -261,8 +311,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
     const double* __restrict__ lognorm, float* __restrict__ ll, int ll_stride,
     const int64_t* __restrict__ frame_off, int n_utts, const unsigned long long* __restrict__ utt_mask,
     const int64_t* __restrict__ pair_first) {
-    __shared__ float tile[EM_WAVES][64][EM_RUN];
+    __shared__ __attribute__((aligned(16))) float lds[EM_WAVES][EM_LDS_FLOATS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float (*tile)[EM_RUN] = (float (*)[EM_RUN])lds[wave];
     const int col = lane & 15, grp = lane >> 4;
     const int64_t n_pairs = (int64_t)em_uniform((unsigned long long)pair_first[n_utts]);
     const int64_t n_waves = (int64_t)gridDim.x * EM_WAVES, me = (int64_t)blockIdx.x * EM_WAVES + wave;
@@ -318,7 +369,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
         const int n_rows = T - 64 * k < 64 ? T - 64 * k : 64;          // rows of the tile that belong to the utterance
         if (f0 != loaded) {
             loaded = f0;
-            em_load_frames(x, feats, f0, total_frames, col, grp);
+            em_load_frames(x, lds[wave], feats, f0, total_frames, lane, col, grp);
         }
 
         constexpr int SLOTS = em_ring<TRI>::SLOTS, RING = em_ring<TRI>::RING;
@@ -350,7 +401,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
             double ss[4];
             em_gaussian<TRI, true>(w, x, cur, nxt, ss);
             const double lp = em_fold(ss, lognorm[s]);
-            tile[wave][lane][(i ^ lane) & (EM_RUN - 1)] = (float)lp;
+            tile[lane][(i ^ lane) & (EM_RUN - 1)] = (float)lp;
             if (lane == i) my_col = s;
             s = s_next;
         }
@@ -358,8 +409,10 @@ __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < cnt) {
-            for (int r = 0; r < n_rows; ++r)
-                ll[(f0 + r) * ll_stride + my_col] = tile[wave][r][(lane ^ r) & (EM_RUN - 1)];
+            float* dst = ll + f0 * ll_stride + my_col;
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r)
+                if (r < n_rows) dst[(int64_t)r * ll_stride] = tile[r][(lane ^ r) & (EM_RUN - 1)];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -119,8 +119,11 @@ def _host_threads() -> int:
     return max(1, min(n, 16))
 
 
+_factor_executor = None
+
+
 def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Optional[int] = None,
-                       shard: Optional[Tuple[int, int]] = None) -> List[MultivariateNormal]:
+                       shard: Optional[Tuple[int, int]] = None, meanwhile=None) -> List[MultivariateNormal]:
     """``[MultivariateNormal.from_means_covariances(m, c) for m, c in zip(means, covariances)]`` as one batch
     (hidden_markov_model.py:283-292 builds one frozen SciPy distribution per state, one after the other).
 
@@ -132,7 +135,8 @@ def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Opti
     the same pass.  Errors are raised for the first failing state, with the serial path's exception types.
 
     ``shard = (rank, world)``: this process factors states rank, rank + world, ... and the results of all
-    processes are exchanged with one all-gather (every process must make the same call)."""
+    processes are exchanged with one all-gather (every process must make the same call).
+    ``meanwhile``: a callable run on the calling thread while the factorisation is under way."""
     import scipy.linalg.cython_lapack as lapack
 
     from . import _lsr_pyhelper as H          # built by the Makefile next to this file
@@ -150,8 +154,22 @@ def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Opti
     # a matrix with NaN or infinite entries never reaches LAPACK (scipy.linalg.eigh(check_finite=True))
     safe = cov if finite.all() else np.where(finite[:, None, None], cov, np.eye(d))
     caps = lapack.__pyx_capi__
-    H.factor_batch(caps["dsyevr"], caps["dgeqrf"], np.ascontiguousarray(safe), lam, whiten, tri, status, S, d, first, step,
-                   threads or min(_host_threads(), 6))
+    args = (caps["dsyevr"], caps["dgeqrf"], np.ascontiguousarray(safe), lam, whiten, tri, status, S, d, first, step,
+            threads or min(_host_threads(), 6))
+    if meanwhile is None:
+        H.factor_batch(*args)
+    else:
+        # the extension releases the GIL for the whole factorisation: the caller's Python work runs beside it
+        global _factor_executor
+        if _factor_executor is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            _factor_executor = ThreadPoolExecutor(max_workers=1, thread_name_prefix="lsr-factor")
+        pending = _factor_executor.submit(H.factor_batch, *args)
+        try:
+            meanwhile()
+        finally:
+            pending.result()
     if step > 1:
         from .distributed import all_gather_strided
 
@@ -898,14 +916,16 @@ class HiddenMarkovModelTrainContinuous:
         iteration divides by the number of ranks like the device work does."""
         if not models:
             return
-        for m in models:
-            m._log_transition_probs = LogTransitionProbabilities.from_transition_probability(m._transition_probs)
         means = np.concatenate([m._means for m in models], axis=0)
         covs = np.concatenate([m._covariances for m in models], axis=0)
         from .distributed import is_active, rank_world
 
+        def log_transitions():
+            for m in models:
+                m._log_transition_probs = LogTransitionProbabilities.from_transition_probability(m._transition_probs)
+
         shard = rank_world() if self.shard_factorization and is_active() else None
-        gaussians = factor_covariances(means, covs, shard=shard)
+        gaussians = factor_covariances(means, covs, shard=shard, meanwhile=log_transitions)
         lo = 0
         for m in models:
             m._multivariate_normals = gaussians[lo:lo + m._means.shape[0]]
@@ -927,20 +947,38 @@ class HiddenMarkovModelTrainContinuous:
         were reached are refreshed together afterwards (_refresh_inference_weights)."""
         reached: List[HiddenMarkovModelTrainable] = []
         stop: Optional[BaseException] = None
-        for lab in self._models_loaded:
-            m = self._trainable_models[lab]
+        # the arithmetic of HiddenMarkovModelTrainable._m_step for the states of all models at once (element by
+        # element the same operations, so the same bits); what stays per model is the control flow
+        models = [self._trainable_models[lab] for lab in self._models_loaded]
+        d = sum_x.shape[1]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mean64 = sum_x / count[:, None]
+            new_means = mean64.astype(np.float32)
+            n = count[:, None, None]
+            cov = ((sum_xx - n * (mean64[:, :, None] * mean64[:, None, :])) / (n - 1) + np.eye(d) * 0.001).astype(np.float32)
+        old_means = np.concatenate([m._means for m in models], axis=0)
+        close = np.isclose(new_means, old_means).all(axis=1) if old_means.shape == new_means.shape else None
+        for lab, m in zip(self._models_loaded, models):
             lo, hi = base[lab], base[lab] + m.num_of_states
             reached.append(m)
-            try:
+            if close is None:                         # layout and statistics disagree: the per-model form reports it
                 m._m_step(count[lo:hi], sum_x[lo:hi], sum_xx[lo:hi], trans[lo:hi, lo:hi])
-            except HiddenMarkovModelTrainable.HMMTrainConverge as e:
+                continue
+            if np.any(count[lo:hi] == 0):
+                stop = HiddenMarkovModelTrainable.HMMTrainMeanFail()
+                break
+            if close[lo:hi].all():                    # np.allclose(new, old): the model keeps all its parameters
                 self._num_of_finished_models += 1
                 if self._num_of_finished_models == len(self._trainable_models):
-                    stop = e
+                    stop = HiddenMarkovModelTrainable.HMMTrainConverge()
                     break
-            except HiddenMarkovModelTrainable.HMMTrainMeanFail as e:
-                stop = e
-                break
+                continue
+            m._means = new_means[lo:hi]
+            m._covariances = cov[lo:hi]
+            block = trans[lo:hi, lo:hi]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                probs = (block / np.sum(block, axis=1, keepdims=True)).astype(np.float32)
+            m._transition_probs = TransitionProbabilities.from_transition_probability(probs)
         self._refresh_inference_weights(reached)
         if stop is not None:
             raise stop

@@ -223,3 +223,50 @@ def test_batched_factorisation_carries_the_bits_of_the_serial_path():
     bad[1, 0, 0] = np.nan
     with pytest.raises(ValueError, match="infs or NaNs"):
         factor_covariances(mu, bad)
+
+
+def test_fused_m_steps_equal_the_per_model_form():
+    """HiddenMarkovModelTrainContinuous._m_steps does the arithmetic of all word models in one pass; model by model
+    (HiddenMarkovModelTrainable._m_step + _update_inference_weights, the reference's loop, hidden_markov_model.py:754-770)
+    must give the same bits, including a model that reports convergence and keeps its parameters."""
+    import numpy as np
+
+    from test_distributed_cpu import _continuous_trainer, _word_stats
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainable
+
+    sizes, count, sum_x, sum_xx, trans = _word_stats(31)
+    fused, loop = _continuous_trainer(sizes), _continuous_trainer(sizes)
+    # make model "B" converge: its current means already equal the new ones
+    lo = sizes[0]
+    for tc in (fused, loop):
+        tc._trainable_models["B"]._means = (sum_x[lo:lo + sizes[1]] / count[lo:lo + sizes[1], None]).astype(np.float32)
+    base, _ = fused._layout()
+    fused._m_steps(base, count, sum_x, sum_xx, trans)
+    for lab in loop._models_loaded:
+        m = loop._trainable_models[lab]
+        a, b = base[lab], base[lab] + m.num_of_states
+        try:
+            m._m_step(count[a:b], sum_x[a:b], sum_xx[a:b], trans[a:b, a:b])
+        except HiddenMarkovModelTrainable.HMMTrainConverge:
+            loop._num_of_finished_models += 1
+        finally:
+            m._update_inference_weights()
+    assert fused._num_of_finished_models == loop._num_of_finished_models == 1
+    for lab in loop._models_loaded:
+        f, l = fused._trainable_models[lab], loop._trainable_models[lab]
+        assert np.array_equal(f._means, l._means) and np.array_equal(f._covariances, l._covariances), lab
+        assert np.array_equal(f._transition_probs.to_array(), l._transition_probs.to_array(), equal_nan=True), lab
+        assert np.array_equal(f._log_transition_probs.to_array(), l._log_transition_probs.to_array(), equal_nan=True), lab
+        assert np.array_equal(f._log_transition_probs.band(), l._log_transition_probs.band(), equal_nan=True), lab
+        for g, h in zip(f._multivariate_normals, l._multivariate_normals):
+            assert np.array_equal(g.whiten, h.whiten) and g.log_pdet == h.log_pdet and np.array_equal(g.mean, h.mean), lab
+    # a state without frames stops at its model; the models before it are updated, those after it are not
+    bad = count.copy()
+    bad[lo] = 0
+    tc = _continuous_trainer(sizes)
+    before_c = tc._trainable_models["C"]._means.copy()
+    import pytest
+    with pytest.raises(HiddenMarkovModelTrainable.HMMTrainMeanFail):
+        tc._m_steps(base, bad, sum_x, sum_xx, trans)
+    assert np.array_equal(tc._trainable_models["A"]._means, fused._trainable_models["A"]._means)
+    assert np.array_equal(tc._trainable_models["C"]._means, before_c)

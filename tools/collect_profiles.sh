@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmc_* gpurun_out/prof_bench   # on the GPU box; delete the local copies too before the call
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python3 bench.py --no-cpu-baseline --no-h2d > gpurun_out/prof_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python3 bench.py --no-cpu-baseline --no-h2d --no-other-configs > gpurun_out/prof_bench.log 2>&1
 tools/pmc_pass.sh a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS > /dev/null
 tools/pmc_pass.sh b SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS > /dev/null
 tools/pmc_pass.sh f FETCH_SIZE > /dev/null

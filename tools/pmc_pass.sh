@@ -4,7 +4,7 @@
 set -e
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-h2d > gpurun_out/pmc_$tag.log 2>&1
+timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-h2d --no-other-configs > gpurun_out/pmc_$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]
