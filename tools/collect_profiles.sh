@@ -11,5 +11,9 @@ tools/pmc_pass.sh f FETCH_SIZE > /dev/null
 tools/pmc_pass.sh w WRITE_SIZE > /dev/null
 tools/pmc_pass.sh t TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum > /dev/null
 tools/pmc_pass.sh m SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE > /dev/null
-timeout -k 10 400 python3 bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench_line.err
+# kernel trace of continuous-training iterations (config 4) and the host-phase breakdown of the same loop
+rm -rf gpurun_out/prof_train
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o train -- python3 tools/prof_train.py 10 > gpurun_out/prof_train_traced.log 2>&1
+timeout -k 10 300 python3 tools/prof_train.py 20 > gpurun_out/prof_train.txt 2>&1
+timeout -k 10 500 python3 bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench_line.err
 tail -c 600 gpurun_out/bench_line.json

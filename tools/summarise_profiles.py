@@ -16,6 +16,11 @@ for tag in "abfwtm":
 stats = glob.glob("gpurun_out/prof_bench/**/*kernel_stats.csv", recursive=True)
 if stats:
     shutil.copy(stats[0], f"{dst}/bench_kernel_stats.csv")
+stats = glob.glob("gpurun_out/prof_train/**/*kernel_stats.csv", recursive=True)
+if stats:
+    shutil.copy(stats[0], f"{dst}/train_iteration_kernel_stats.csv")
+if os.path.exists("gpurun_out/prof_train.txt"):
+    shutil.copy("gpurun_out/prof_train.txt", f"{dst}/train_iteration_host_phases.txt")
 if os.path.exists("gpurun_out/bench_line.json"):
     shutil.copy("gpurun_out/bench_line.json", f"{dst}/bench_line.json")
 f = json.load(open(f"{dst}/pmc_pass_f.json")); w = json.load(open(f"{dst}/pmc_pass_w.json"))
