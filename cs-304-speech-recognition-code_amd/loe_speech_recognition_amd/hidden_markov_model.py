@@ -191,13 +191,20 @@ def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Opti
             raise ValueError("The input matrix must be symmetric positive semidefinite.")
         raise np.linalg.LinAlgError(
             "When `allow_singular is False`, the input matrix must be symmetric positive definite.")
-    out: List[MultivariateNormal] = []
+    out = _GaussianBatch()
     pdet = log_pdet.tolist()
     for s in range(S):
         g = MultivariateNormal()
         g.mean, g.whiten, g.log_pdet, g.dim_of_features, g.tri = means[s], whiten[s], pdet[s], d, tri[s]
         out.append(g)
+    # the arrays the objects are views of, in the form Engine.set_model takes (see stack_gaussians / stack_rotated)
+    out.stacked = (means, whiten, d * _LOG_2PI + log_pdet, None, 1, tri)
     return out
+
+
+class _GaussianBatch(list):
+    """List of MultivariateNormal objects of one factor_covariances call, with the stacked arrays they view."""
+    stacked = None
 
 
 def stack_rotated(gaussians: Sequence) -> Optional[np.ndarray]:
@@ -916,28 +923,38 @@ class HiddenMarkovModelTrainContinuous:
         iteration divides by the number of ranks like the device work does."""
         if not models:
             return
-        means = np.concatenate([m._means for m in models], axis=0)
-        covs = np.concatenate([m._covariances for m in models], axis=0)
+        # a model that reported convergence kept its parameter arrays: its Gaussians are the ones already there
+        # (the reference recomputes them from the unchanged parameters, with the same result)
+        done = self.__dict__.setdefault("_factored", {})
+        stale = [m for m in models
+                 if done.get(m.label, (None,))[0] is not m._means or done[m.label][1] is not m._covariances
+                 or done[m.label][2] is not m._multivariate_normals]
         from .distributed import is_active, rank_world
 
         def log_transitions():
             for m in models:
                 m._log_transition_probs = LogTransitionProbabilities.from_transition_probability(m._transition_probs)
 
-        shard = rank_world() if self.shard_factorization and is_active() else None
-        gaussians = factor_covariances(means, covs, shard=shard, meanwhile=log_transitions)
-        lo = 0
-        for m in models:
-            m._multivariate_normals = gaussians[lo:lo + m._means.shape[0]]
-            lo += m._means.shape[0]
+        if stale:
+            means = np.concatenate([m._means for m in stale], axis=0)
+            covs = np.concatenate([m._covariances for m in stale], axis=0)
+            shard = rank_world() if self.shard_factorization and is_active() else None
+            gaussians = factor_covariances(means, covs, shard=shard, meanwhile=log_transitions)
+            lo = 0
+            for m in stale:
+                m._multivariate_normals = gaussians[lo:lo + m._means.shape[0]]
+                lo += m._means.shape[0]
+                done[m.label] = (m._means, m._covariances, m._multivariate_normals)
+        else:
+            log_transitions()
+        self.__dict__["_factored_states"] = sum(m._means.shape[0] for m in stale)
         if [m.label for m in models] == list(self._models_loaded):
-            d = means.shape[1]
-            log_norm = np.array([g.log_norm for g in gaussians], dtype=np.float64)
-            # rows of the gaussians are views of these stacks: nothing is copied
-            self.__dict__["_stack_cache"] = {
-                "lists": [m._multivariate_normals for m in models],
-                "arrays": (np.stack([g.mean for g in gaussians]), np.stack([g.whiten for g in gaussians]), log_norm, None, 1,
-                           np.stack([g.tri for g in gaussians]))}
+            if len(stale) == len(models):
+                arrays = gaussians.stacked                    # every model was factored: the batch arrays as they are
+            else:
+                flat = [g for m in models for g in m._multivariate_normals]
+                arrays = stack_gaussians(flat) + (stack_rotated(flat),)
+            self.__dict__["_stack_cache"] = {"lists": [m._multivariate_normals for m in models], "arrays": arrays}
 
     def _m_steps(self, base, count, sum_x, sum_xx, trans) -> None:
         """hidden_markov_model.py:754-770, including the never-reset convergence counter: a model whose means

@@ -287,3 +287,49 @@ def test_gaussian_mixture_emissions_and_decode(n_mix):
     one = models[0].predict(x[:40])
     s1, p1, _ = O.viterbi_chain_fast(got[:40, :5], O.band_from_ltp(O.LogTransRef.from_probs(trans["1"]), 5))
     assert one[0] == s1 and np.array_equal(one[1], p1)
+
+
+def test_resident_model_slots(words):
+    """lsr_model_slot: several uploaded models stay on the device and a switch selects one without a new upload.
+    Emission scores after switching back and forth equal those of a fresh upload of the same model, an empty slot
+    refuses to compute, and the engine's token -> slot table survives more models than slots (least recently used
+    goes first)."""
+    import ctypes
+
+    from loe_speech_recognition_amd import _native
+    from loe_speech_recognition_amd.hidden_markov_model import stack_gaussians
+
+    eng = _native.get_engine()
+    rng = np.random.default_rng(17)
+    x = [(1.5 * rng.standard_normal((40, 39))).astype(np.float32)]
+    fb = eng.feature_batch(x)
+    labels = sorted(words)
+    sets = [stack_gaussians(words[lab]._multivariate_normals) for lab in labels]
+    fresh = []
+    for arrays in sets:                                     # reference results: anonymous uploads (slot 0)
+        eng.set_model(None, *arrays)
+        fresh.append(eng.emission(fb).cpu().numpy())
+    tokens = [_native.new_token() for _ in sets]
+    for rounds in range(2):                                 # more models than slots: eviction and re-upload on the way
+        for tok, arrays, ref in zip(tokens, sets, fresh):
+            eng.set_model(tok, *arrays)
+            assert np.array_equal(eng.emission(fb).cpu().numpy(), ref, equal_nan=True)
+    assert len(eng._resident) <= eng.MODEL_SLOTS - 1
+    # the last models are resident: selecting them uploads nothing (the arrays are not even looked at)
+    for tok, ref in list(zip(tokens, fresh))[-3:]:
+        eng.set_model(tok, None, None, None)
+        assert np.array_equal(eng.emission(fb).cpu().numpy(), ref, equal_nan=True)
+    # C ABI: slot range is checked, an empty slot holds no model
+    assert eng.lib.lsr_model_slot(eng.ctx, 8) == -1 and eng.lib.lsr_model_slot(eng.ctx, -1) == -1
+    used = {v[0] for v in eng._resident.values()} | {0}
+    free = [k for k in range(eng.MODEL_SLOTS) if k not in used]
+    if free:
+        eng._select_slot(free[0])
+        try:
+            out = eng.empty((64, 64), eng.torch.float32)
+            rc = eng.lib.lsr_emission_batch(eng.ctx, ctypes.c_void_p(fb.feats.data_ptr()), fb.total_frames,
+                                            ctypes.c_void_p(out.data_ptr()))
+            assert rc == -4                                  # LSR_ERR_STATE: no model uploaded
+        finally:
+            eng._select_slot(0)
+            eng._model_token = None

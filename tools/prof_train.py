@@ -61,12 +61,15 @@ def main():
     eng.profile_reset()
     eng.profile_enable(True)
     t = time.perf_counter()
+    factored = []
     for _ in range(n_iter):
         tc._iteration(None)
+        factored.append(tc.__dict__.get("_factored_states"))
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t) / n_iter
     eng.profile_enable(False)
-    print(f"per iteration {wall * 1e3:.3f} ms over {n_iter} iterations, {len(sigs)} clips")
+    print(f"per iteration {wall * 1e3:.3f} ms over {n_iter} iterations, {len(sigs)} clips; states factored per iteration "
+          f"(models whose means moved): {factored}; models that reported convergence so far: {tc._num_of_finished_models}")
     total_k = 0.0
     for k in ("emission", "viterbi", "stats"):
         ms, n = eng.profile_get(k)
