@@ -884,16 +884,7 @@ class HiddenMarkovModelTrainContinuous:
         run, hidden_markov_model.py:614-634).  Paths, slots and statistics stay on the device; one
         packed float64 vector comes back (after the all-reduce when several ranks train together)."""
         eng = _native.get_engine()
-        t = eng.torch
-        fb, owner = self._prepare(labeled_mfccs)
-        paths, off, ids, ordinal, n_total = self._align(fb, owner)
-        d_off, d_ids = eng.last_chain
-        cache = self.__dict__["_chain_cache"]
-        if "d_ordinal" not in cache:
-            cache["d_ordinal"] = eng.to_device(ordinal.astype(np.int32))
-        slots, trans = eng.remux_slots(paths, fb, d_off, d_ids, cache["d_ordinal"], n_total, drop_last_run=True)
-        count, sum_x, sum_xx = eng.accumulate_stats(fb.feats, slots, fb.total_frames, n_total)
-        stats = t.cat([count, sum_x.reshape(-1), sum_xx.reshape(-1), trans.reshape(-1).to(t.float64)])
+        stats, n_total = self._local_statistics(labeled_mfccs)
         stats = all_reduce_stats(stats)
         stats = eng.to_host_pinned(stats)
         d = _native.DIM
@@ -903,6 +894,22 @@ class HiddenMarkovModelTrainContinuous:
         trans = stats[n_total * (1 + d + d * d):].reshape(n_total, n_total)
         base, _ = self._layout()
         self._m_steps(base, count, sum_x, sum_xx, trans)
+
+    def _local_statistics(self, labeled_mfccs: Optional[Dict[str, List[np.ndarray]]]):
+        """This process's share of an iteration before the exchange: forced alignment of its utterances, re-mux,
+        and the packed float64 device vector (count [S], sum_x [S, 39], sum_xx [S, 39, 39], transition counts
+        [S, S]) that the ranks add up.  Returns (vector, S)."""
+        eng = _native.get_engine()
+        t = eng.torch
+        fb, owner = self._prepare(labeled_mfccs)
+        paths, off, ids, ordinal, n_total = self._align(fb, owner)
+        d_off, d_ids = eng.last_chain
+        cache = self.__dict__["_chain_cache"]
+        if "d_ordinal" not in cache:
+            cache["d_ordinal"] = eng.to_device(ordinal.astype(np.int32))
+        slots, trans = eng.remux_slots(paths, fb, d_off, d_ids, cache["d_ordinal"], n_total, drop_last_run=True)
+        count, sum_x, sum_xx = eng.accumulate_stats(fb.feats, slots, fb.total_frames, n_total)
+        return t.cat([count, sum_x.reshape(-1), sum_xx.reshape(-1), trans.reshape(-1).to(t.float64)]), n_total
 
     def _stacked_gaussians(self, models: Sequence[HiddenMarkovModelTrainable]):
         """Arguments of Engine.set_model for the Gaussians of all word models in layout order.  After an

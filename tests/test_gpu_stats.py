@@ -133,3 +133,71 @@ def test_remux_slots_and_transition_counts(n_states, drop):
     assert np.array_equal(slots.cpu().numpy(), want_slots)
     assert np.array_equal(trans.cpu().numpy(), want_trans)
     assert want_trans.sum() > 1000
+
+
+def test_full_size_training_iteration_properties():
+    """Config 4 at its full size (12 000 clips of 1-7 digits, 2.5 M frames) through size-independent properties:
+    (i) forced-alignment paths are the same bits whether the emission pass scores every state or only the states
+    the chains can reach; (ii) the statistics of the whole corpus equal the sum of the statistics of two contiguous
+    shards - what the all-reduce of a two-rank run adds up - exactly for the counts and to float64 rounding for the
+    sums; (iii) the M-step from the summed shards gives the models of the single-process iteration."""
+    import multiprocessing as mp
+
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainContinuous, _native, synthetic
+
+    with mp.get_context("fork").Pool(8) as pool:
+        parts = pool.starmap(synthetic.batch, [(4, 400, [1, 2, 3, 4, 5, 7], 400 * k) for k in range(30)])
+    sigs = [s for p in parts for s in p[0]]
+    truth = [d for p in parts for d in p[1]]
+    assert len(sigs) == 12000
+    eng = _native.get_engine()
+    t = eng.torch
+    fb = eng.mfcc(eng.audio_batch(sigs))
+    models = synthetic.load_word_models()
+
+    def trainer():
+        tc = HiddenMarkovModelTrainContinuous(isTqdm=False)
+        for lab in synthetic.WORDS + ["S"]:
+            tc.add_model(models[lab])
+        return tc
+
+    def shard(a, b):
+        f0, f1 = int(fb.host_off[a]), int(fb.host_off[b])
+        off = eng.to_device((fb.host_off[a:b + 1] - fb.host_off[a]).astype(np.int64))
+        return _native.FeatureBatch(fb.feats[f0:f1], off, fb.lengths[a:b])
+
+    # (i) both emission forms, full size
+    whole = trainer()
+    whole.use_device_batch(fb, truth)
+    paths = {}
+    for mode in ("all", "reachable"):
+        eng.chain_emission_mode(mode)
+        try:
+            paths[mode] = whole._align(fb, truth)[0].clone()
+        finally:
+            eng.chain_emission_mode("auto")
+    assert t.equal(paths["all"], paths["reachable"])
+    # (ii) whole corpus against the sum of two shards
+    stats, n_states = whole._local_statistics(None)
+    stats = stats.cpu().numpy()
+    total = np.zeros_like(stats)
+    for a, b in ((0, 5000), (5000, 12000)):
+        part = trainer()
+        part.use_device_batch(shard(a, b), truth[a:b])
+        total += part._local_statistics(None)[0].cpu().numpy()
+    n_int = n_states                                               # counts, then (after the sums) transition counts
+    assert np.array_equal(stats[:n_int], total[:n_int]) and stats[:n_int].sum() > 2.0e6
+    assert np.array_equal(stats[-n_states * n_states:], total[-n_states * n_states:])
+    assert np.allclose(stats, total, rtol=1e-12, atol=1e-6)
+    # (iii) the M-step of the summed shards against the single-process iteration
+    d = 39
+    base, _ = whole._layout()
+    summed = trainer()
+    summed._m_steps(base, total[:n_states], total[n_states:n_states * (1 + d)].reshape(n_states, d),
+                    total[n_states * (1 + d):n_states * (1 + d + d * d)].reshape(n_states, d, d),
+                    total[-n_states * n_states:].reshape(n_states, n_states))
+    whole._iteration(None)
+    for lab in whole._models_loaded:
+        a, b = whole._trainable_models[lab], summed._trainable_models[lab]
+        assert np.allclose(a._means, b._means, rtol=1e-5, atol=1e-6) and np.allclose(a._covariances, b._covariances, rtol=1e-4, atol=1e-6)
+        assert np.array_equal(a._transition_probs.to_array(), b._transition_probs.to_array(), equal_nan=True)
