@@ -345,7 +345,6 @@ __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
         }
     }
 
-    int64_t loaded = -1;                                     // first frame of the tile whose frames are in x[][]
     double x[4][LSR_KSTEPS];
     while (p < p_end) {
         if ((m0 | m1) == 0) {                 // tile finished (p < p_end <= n_pairs: some later tile has states left)
@@ -367,10 +366,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 3) void lsr_emission_masked_kernel(
         p += cnt;
         const int64_t f0 = f_utt + 64 * (int64_t)k;
         const int n_rows = T - 64 * k < 64 ? T - 64 * k : 64;          // rows of the tile that belong to the utterance
-        if (f0 != loaded) {
-            loaded = f0;
-            em_load_frames(x, lds[wave], feats, f0, total_frames, lane, col, grp);
-        }
+        // every run loads its tile's frames: a tile with more than EM_RUN selected states (two runs) is the rare case
+        // here, and an unconditional load keeps the frame registers from being carried across the branch
+        em_load_frames(x, lds[wave], feats, f0, total_frames, lane, col, grp);
 
         constexpr int SLOTS = em_ring<TRI>::SLOTS, RING = em_ring<TRI>::RING;
         const int a_idx = (lane >> 4) * 4 + (lane & 3);

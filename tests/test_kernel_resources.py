@@ -1,6 +1,6 @@
-"""Register and occupancy budget of the two hot kernels, read from the compiler's resource remarks (no GPU needed).
+"""Register and occupancy budget of the hot kernels, read from the compiler's resource remarks (no GPU needed).
 
-Both kernels are tuned to three wavefronts per SIMD without spills; for the mel power kernel a spill is not a small
+They are tuned to three wavefronts per SIMD without spills; for the mel power kernel a spill is not a small
 loss: scratch reloads share the in-order memory counter with the sample prefetch and stall on it.  A toolchain or
 source change that breaks the budget should fail here, not show up as a slower bench line."""
 import os
@@ -42,7 +42,8 @@ def _resources(source, tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
 @pytest.mark.parametrize("source,pattern,max_vgprs", [("lsr_mfcc.hip", "lsr_mel_power_kernel", 168),
-                                                      ("lsr_emission.hip", "lsr_emission_kernelILb1ELb0E", 168)])
+                                                      ("lsr_emission.hip", "lsr_emission_kernelILb1ELb0E", 168),
+                                                      ("lsr_emission.hip", "lsr_emission_masked_kernelILb1E", 168)])
 def test_three_wavefronts_per_simd_without_spills(tmp_path, source, pattern, max_vgprs):
     kernels = {k: v for k, v in _resources(source, tmp_path).items() if pattern in k}
     assert kernels, "kernel not found in the compiler remarks"
