@@ -240,8 +240,15 @@ extern "C" int lsr_ctx_create(int device, lsr_ctx** out) {
     if (!out) return LSR_ERR_ARG;
     *out = nullptr;
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return LSR_ERR_HIP;
-    if (hipSetDevice(device) != hipSuccess) return LSR_ERR_HIP;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device < 0 || device >= count) {
+        fprintf(stderr, "lsr_ctx_create(%d): hipGetDeviceCount -> %s, %d device(s)\n", device, hipGetErrorString(e), count);
+        return LSR_ERR_HIP;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        fprintf(stderr, "lsr_ctx_create(%d): hipSetDevice -> %s\n", device, hipGetErrorString(e));
+        return LSR_ERR_HIP;
+    }
     lsr_ctx* ctx = new lsr_ctx();
     ctx->device = device;
     int cus = 0;

@@ -122,6 +122,11 @@ def load_library():
             raise NativeLibraryMissing(
                 f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(os.path.dirname(LIB_PATH))}` "
                 "(or __graft_entry__.build()).  There is no CPU fallback.")
+        # PyTorch's ROCm build ships its own copy of the HIP runtime.  It has to be in the process before this
+        # library is: loaded the other way round, the library binds to the system's runtime, and that second
+        # runtime finds no device once PyTorch's has initialised the GPU.
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(LIB_PATH)
         _declare(lib)
         _lib = lib
