@@ -743,6 +743,13 @@ class HiddenMarkovModelTrainContinuous:
         obj._models_loaded = models_to_load
         return obj
 
+    def __getstate__(self):
+        # device buffers and what was derived from them stay behind: a copy rebuilds them on first use
+        state = dict(self.__dict__)
+        for key in ("_data_cache", "_chain_cache", "_stack_cache", "_factored", "_factored_states"):
+            state.pop(key, None)
+        return state
+
     def add_model(self, m: HiddenMarkovModelTrainable) -> None:
         """Register a word model the way from_folder does (hidden_markov_model.py:692-707): the
         inference weights are kept, the trainable parameters restart from zeros / 0.01 I /

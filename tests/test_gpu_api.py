@@ -63,6 +63,22 @@ def test_objects_pickle_and_keep_working(words):
     mc._models = [words[lab] for lab in synthetic.WORDS]
     mc.predict(feats[0])
     assert pickle.loads(pickle.dumps(mc)).scores_batch(feats).shape == (4, 11)
+    # a continuous trainer that has iterated (device batch, chain tables, factorisation caches) pickles to its models
+    from loe_speech_recognition_amd import HiddenMarkovModelTrainContinuous
+
+    tc = HiddenMarkovModelTrainContinuous(isTqdm=False)
+    for lab in synthetic.WORDS + ["S"]:
+        tc.add_model(pickle.loads(pickle.dumps(words[lab])))
+    more, more_truth = synthetic.batch(3, 64, 4, start=8100)               # every word occurs: no state stays without frames
+    assert set("".join(more_truth)) == set(synthetic.WORDS)
+    labeled = synthetic.group_by_label(MFCC.batch(more, 16000), more_truth)
+    tc._iteration(labeled)
+    clone = pickle.loads(pickle.dumps(tc))
+    assert "_chain_cache" not in clone.__dict__ and "_data_cache" not in clone.__dict__
+    tc._iteration(labeled)
+    clone._iteration(labeled)
+    for lab in tc._models_loaded:
+        assert np.array_equal(tc._trainable_models[lab]._means, clone._trainable_models[lab]._means), lab
 
 
 def test_isolated_classifier_on_word_clips(words):
