@@ -120,11 +120,16 @@ __global__ __launch_bounds__(64) void lsr_slot_scatter_kernel(const int32_t* __r
     }
 }
 
-__device__ __forceinline__ void ss_load(const float* __restrict__ feats, const int32_t* __restrict__ order, int pos,
-                                        int end, int c, double (&x)[3]) {
+// frame index at position pos of the sorted list (-1 past the end of the part)
+__device__ __forceinline__ int ss_index(const int32_t* __restrict__ order, int pos, int end) {
+    return pos < end ? order[pos] : -1;
+}
+
+// the lane's three values of frame `frame` (zeros for -1)
+__device__ __forceinline__ void ss_load(const float* __restrict__ feats, int frame, int c, double (&x)[3]) {
     x[0] = x[1] = x[2] = 0.0;
-    if (pos < end) {
-        const float* row = feats + (size_t)order[pos] * LSR_DIM;
+    if (frame >= 0) {
+        const float* row = feats + (size_t)frame * LSR_DIM;
         x[0] = (double)row[c];
         x[1] = (double)row[16 + c];
         x[2] = c < 7 ? (double)row[32 + c] : (c == 7 ? 1.0 : 0.0);       // column 39 is the constant
@@ -152,13 +157,22 @@ __global__ __launch_bounds__(64) void lsr_gram_kernel(const float* __restrict__ 
     v4d acc[SS_TILES];
 #pragma unroll
     for (int t = 0; t < SS_TILES; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    // sixteen frames per iteration (four k-steps of four frames), the next sixteen in flight meanwhile
+    // sixteen frames per iteration (four k-steps of four frames).  A frame is reached through two dependent loads (its
+    // index in the sorted list, then its row), so the rows of the next sixteen frames and the indices of the sixteen
+    // after those are in flight while the current ones are multiplied
     double x[4][3], nx[4][3];
+    int ni[4], nni[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ss_load(feats, order, first + 4 * u + g, end, c, x[u]);
+    for (int u = 0; u < 4; ++u) {
+        ss_load(feats, ss_index(order, first + 4 * u + g, end), c, x[u]);
+        ni[u] = ss_index(order, first + 16 + 4 * u + g, end);
+    }
     for (int pos = first; pos < end; pos += 16) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ss_load(feats, order, pos + 16 + 4 * u + g, end, c, nx[u]);
+        for (int u = 0; u < 4; ++u) {
+            nni[u] = ss_index(order, pos + 32 + 4 * u + g, end);
+            ss_load(feats, ni[u], c, nx[u]);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][0], x[u][0], acc[0], 0, 0, 0);
@@ -169,9 +183,11 @@ __global__ __launch_bounds__(64) void lsr_gram_kernel(const float* __restrict__ 
             acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][2], x[u][2], acc[5], 0, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) x[u][k] = nx[u][k];
+            ni[u] = nni[u];
+        }
     }
     v4d* out = partial + ((size_t)b * SS_TILES) * 64 + lane;
 #pragma unroll
