@@ -109,8 +109,9 @@ def emission_gmm_ref(x: np.ndarray, weights: np.ndarray, gaussians: Sequence[Seq
     (deprecated/gaussian_mixture_model.py:159-164): log_prob = -inf, then
     log_prob = np.logaddexp(log_prob, np.log(w_m) + logpdf_m(x)) component by component in
     float64; rounded to float32 like the live code's MultivariateNormal.log_pdf.
-    PARITY UNPINNED: that module is dead code (not importable: it imports a function that does
-    not exist and runs a script at import), so no reference output exists for it."""
+    Pinned by tests/golden/gmm_g9_emission.npz: values returned by the reference's own
+    HMM_GMM.log_emission_prob (tools/make_golden_gmm.py executes that module, which is dead code in
+    the reference and fails in its script part, up to the point where the class exists)."""
     T = x.shape[0]
     out = np.empty((T, len(gaussians)), dtype=np.float32)
     with np.errstate(divide="ignore"):

@@ -243,7 +243,8 @@ def test_continuous_iteration_on_synthetic_speech_matches_oracle(words):
 @pytest.mark.parametrize("n_mix", [2, 4])
 def test_gaussian_mixture_emissions_and_decode(n_mix):
     """Mixture emissions (log-sum over components) against the oracle's restatement of
-    deprecated/gaussian_mixture_model.py:159-164, and a loop decode that uses them."""
+    deprecated/gaussian_mixture_model.py:159-164 (itself pinned by the reference's values in gmm_g9_emission.npz),
+    and a loop decode that uses them."""
     from loe_speech_recognition_amd import (GaussianMixture, HiddenMarkovModel, HiddenMarkovModelInference,
                                             LogTransitionProbabilities, TransitionProbabilities, _native)
     from loe_speech_recognition_amd.hidden_markov_model import stack_gaussians

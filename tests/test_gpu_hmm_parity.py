@@ -32,6 +32,29 @@ def test_g1_emission():
     assert v.dtype == np.float32 and abs(v - ref[3, 7]) <= np.spacing(abs(ref[3, 7]))
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g9_mixture_emission(tag):
+    """Mixture emissions against values the reference's own HMM_GMM.log_emission_prob returned
+    (deprecated/gaussian_mixture_model.py:159-164; tests/golden/gmm_g9_emission.npz), rounded to float32 as the
+    live code rounds its emissions: at most one float32 step apart, on few elements."""
+    from loe_speech_recognition_amd import GaussianMixture, _native
+    from loe_speech_recognition_amd.hidden_markov_model import stack_gaussians
+
+    g = load("gmm_g9_emission.npz")
+    mixtures = [GaussianMixture.from_weights_means_covariances(w, m, c)
+                for w, m, c in zip(g[f"{tag}_weights"], g[f"{tag}_means"], g[f"{tag}_cov"])]
+    eng = _native.get_engine()
+    eng.set_model(None, *stack_gaussians(mixtures))
+    x = g[f"{tag}_x"]
+    want = g[f"{tag}_logprob"].astype(np.float32)
+    got = eng.emission(eng.feature_batch([x])).cpu().numpy()[:x.shape[0], :want.shape[1]]
+    assert rel_err(got, want) <= 1e-4
+    assert np.all(np.abs(got - want) <= np.spacing(np.abs(want)))
+    assert np.mean(got != want) < 0.02
+    v = mixtures[1].log_pdf(x[3])
+    assert v.dtype == np.float32 and abs(v - want[3, 1]) <= np.spacing(abs(want[3, 1]))
+
+
 @pytest.mark.parametrize("n", [3, 5])
 def test_g2_single_model(n):
     g = load("hmm_g2_single.npz")

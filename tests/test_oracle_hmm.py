@@ -224,9 +224,30 @@ def _random_gmm(rng, n_states, n_mix):
     return weights, comps
 
 
+def _g9(tag, golden_dir):
+    g = np.load(os.path.join(golden_dir, "gmm_g9_emission.npz"), allow_pickle=False)
+    comps = [[O.GaussianRef(m, c) for m, c in zip(ms, cs)] for ms, cs in zip(g[f"{tag}_means"], g[f"{tag}_cov"])]
+    return g, comps
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g9_mixture_emission_equals_the_reference(golden_dir, tag):
+    """tests/golden/gmm_g9_emission.npz holds what the reference's own HMM_GMM.log_emission_prob returned
+    (deprecated/gaussian_mixture_model.py:159-164, float64; tools/make_golden_gmm.py).  The loop restatement must
+    reproduce those values exactly once rounded to float32 as the live code rounds, the vectorised one to an ulp."""
+    g, comps = _g9(tag, golden_dir)
+    assert "FileNotFoundError" in str(g["module_execution_stopped_at"])      # the class was taken from the real module
+    want = g[f"{tag}_logprob"].astype(np.float32)
+    got = O.emission_gmm_ref(g[f"{tag}_x"], g[f"{tag}_weights"], comps)
+    assert np.array_equal(got, want)
+    assert np.isfinite(want).all() and (g[f"{tag}_weights"][2, 0] == 0.0)   # the zero-weight component drops out
+    fast = O.emission_gmm_fast(g[f"{tag}_x"], g[f"{tag}_weights"], comps)
+    assert np.all(np.abs(fast - want) <= np.spacing(np.abs(want)))
+
+
 def test_gmm_emission_restatements_agree():
-    """Mixture emissions have no reference output (dead code upstream): check the restatement against
-    the definition log sum_m w_m N_m and its vectorised form against the loop form."""
+    """Beyond the fixture: the restatement against the definition log sum_m w_m N_m and its vectorised form against
+    the loop form on further random mixtures."""
     rng = np.random.default_rng(8)
     weights, comps = _random_gmm(rng, 3, 4)
     x = (rng.standard_normal((6, 39)) * 2).astype(np.float32)
