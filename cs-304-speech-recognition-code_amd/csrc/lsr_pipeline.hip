@@ -188,7 +188,9 @@ extern "C" int lsr_recognize_host(lsr_ctx* ctx, const void* const* clips, const 
     if (ctx->n_states / ctx->n_mix != ctx->g_states)
         return lsr_fail(ctx, LSR_ERR_STATE, "lsr_recognize_host: model has %d states, graph %d",
                         ctx->n_states / ctx->n_mix, ctx->g_states);
-    if (chunk_samples <= 0) chunk_samples = (int64_t)24 << 20;      // about 48 MB of int16 / 96 MB of float32 per chunk
+    // measured optimum on the config-3 batch: 96 MB chunks of float32, 24 MB chunks of int16 (smaller chunks start the
+    // first copy earlier, which weighs more when the whole transfer is half as long)
+    if (chunk_samples <= 0) chunk_samples = (int64_t)(audio_is_i16 ? 12 : 24) << 20;
     if (n_threads <= 0) n_threads = 8;
     if (n_threads > 64) n_threads = 64;
     for (int b = 0; b < n_utts; ++b) {

@@ -182,7 +182,7 @@ int lsr_recognize_batch_i16(lsr_ctx* ctx, const int16_t* audio_d, const int64_t*
  * arrays, as the reference's loader delivers them (ti_digits.py:130-134: wavfile.read -> int16, or
  * its float32 conversion): clips[b] points to the n_samples[b] samples of clip b (int16 when
  * audio_is_i16 != 0, else float32) anywhere in host memory - no concatenation is needed.  The clips
- * are packed chunk by chunk (about chunk_samples samples each, <= 0: a default of 24 Mi samples)
+ * are packed chunk by chunk (about chunk_samples samples each, <= 0: a default of 24 Mi samples of float32, 12 Mi of int16)
  * into pinned staging memory by n_threads worker threads (<= 0: 8), uploaded with asynchronous
  * copies on a separate stream, and decoded (lsr_recognize_batch[_i16]) while later chunks are
  * packed and uploaded; three staging slots rotate.  Outputs are HOST arrays, complete when the call
