@@ -114,59 +114,89 @@ static PyObject* array_table(PyObject* self, PyObject* args) {
  *   L        = R^T of U^T = Q R (dgeqrf on U^T, upper triangle kept)            (numpy.linalg.qr(U.T, mode="r").T)
  * status = LAPACK's info of dsyevr (or -1000 when it found fewer than n eigenvalues, -2000 - info for dgeqrf).
  * Matrices first, first + step, ... are processed; the rows of the others are left untouched. */
-typedef void (*dsyevr_fn)(char*, char*, char*, int*, double*, int*, double*, double*, int*, int*, double*, int*, double*,
-                          double*, int*, int*, double*, int*, int*, int*, int*);
-typedef void (*dgeqrf_fn)(int*, int*, double*, int*, double*, double*, int*, int*);
+/* LAPACK's integer arguments are 32 bits wide in SciPy's library (LP64) and 64 bits in the ILP64 build NumPy ships:
+ * the routines are held as untyped pointers and called through the signature that matches (lapack_int). */
+typedef void (*lapack_fn)(void);
+
+struct factor_lib {
+    lapack_fn syevr, geqrf;
+    int ilp64;
+    int lwork, liwork, qwork;     /* workspace sizes of this library's own queries */
+};
 
 struct factor_job {
-    dsyevr_fn syevr;
-    dgeqrf_fn geqrf;
+    struct factor_lib lib[2];      /* lib[1].syevr == NULL: one library only */
     const double* cov;
     double *lam, *whiten, *tri;
     int32_t* status;
     int n, n_mats, first, step;
-    int lwork, liwork, qwork;
     int next;            /* next share to hand out (atomic) */
     int failed;          /* allocation failure */
 };
 
-/* one matrix with the scratch memory at a (doubles) / iw (ints) */
-static void factor_one(const struct factor_job* J, int i, double* a, int* iw) {
-    const int n = J->n;
-    const size_t nn = (size_t)n * n;
-    double *z = a + nn, *work = z + nn, *qw = work + J->lwork, *w = qw + J->qwork, *tau = w + n;
-    int *iwork = iw, *isuppz = iw + J->liwork;
-    const double* c = J->cov + (size_t)i * nn;
-    /* column-major copy of the row-major matrix: a[r + col * n] = C[r][col] */
-    for (int r = 0; r < n; ++r)
-        for (int col = 0; col < n; ++col) a[r + (size_t)col * n] = c[(size_t)r * n + col];
-    char jobz = 'V', range = 'A', uplo = 'L';
-    int nn_ = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = J->lwork, liwork = J->liwork;
-    double vl = 0.0, vu = 1.0, abstol = 0.0;
-    J->syevr(&jobz, &range, &uplo, &nn_, a, &lda, &vl, &vu, &il, &iu, &abstol, &m, w, z, &ldz, isuppz, work, &lwork, iwork,
-             &liwork, &info);
-    if (info == 0 && m != n) info = -1000;
-    double* U = J->whiten + (size_t)i * nn;
-    double* L = J->tri + (size_t)i * nn;
-    for (int j = 0; j < n; ++j) {
-        J->lam[(size_t)i * n + j] = w[j];
-        const double scale = sqrt(1.0 / w[j]);
-        for (int k = 0; k < n; ++k) U[(size_t)k * n + j] = z[k + (size_t)j * n] * scale;
+#define FACTOR_DEFINE(SUFFIX, INT)                                                                                  \
+    typedef void (*dsyevr_##SUFFIX)(char*, char*, char*, INT*, double*, INT*, double*, double*, INT*, INT*, double*,  \
+                                    INT*, double*, double*, INT*, INT*, double*, INT*, INT*, INT*, INT*);            \
+    typedef void (*dgeqrf_##SUFFIX)(INT*, INT*, double*, INT*, double*, double*, INT*, INT*);                        \
+    /* workspace sizes, as scipy.linalg.eigh (dsyevr_lwork) and numpy.linalg.qr (lwork = -1) ask for them */         \
+    static int factor_query_##SUFFIX(struct factor_lib* L, int n_) {                                                 \
+        char jobz = 'V', range = 'A', uplo = 'L';                                                                    \
+        INT n = n_, lda = n_, ldz = n_, il = 1, iu = n_, m = 0, info = 0, lwork = -1, liwork = -1, iwq = 0, isup = 0; \
+        double vl = 0.0, vu = 1.0, abstol = 0.0, wq = 0.0, dummy = 0.0;                                              \
+        ((dsyevr_##SUFFIX)L->syevr)(&jobz, &range, &uplo, &n, &dummy, &lda, &vl, &vu, &il, &iu, &abstol, &m, &dummy,  \
+                                    &dummy, &ldz, &isup, &wq, &lwork, &iwq, &liwork, &info);                         \
+        if (info != 0) return (int)info;                                                                             \
+        INT q_lwork = -1, qinfo = 0;                                                                                 \
+        double qq = 0.0;                                                                                             \
+        ((dgeqrf_##SUFFIX)L->geqrf)(&n, &n, &dummy, &lda, &dummy, &qq, &q_lwork, &qinfo);                             \
+        if (qinfo != 0) return (int)qinfo;                                                                           \
+        L->lwork = (int)wq > 1 ? (int)wq : 1;                                                                        \
+        L->liwork = (int)iwq > 1 ? (int)iwq : 1;                                                                     \
+        L->qwork = (int)qq > n_ ? (int)qq : n_;                                                                      \
+        return 0;                                                                                                    \
+    }                                                                                                                \
+    /* one matrix with the scratch memory at a (doubles) / iw (INTs) */                                              \
+    static void factor_one_##SUFFIX(const struct factor_job* J, const struct factor_lib* L, int i, double* a,        \
+                                    void* iw_) {                                                                     \
+        const int n = J->n;                                                                                          \
+        const size_t nn = (size_t)n * n;                                                                             \
+        double *z = a + nn, *work = z + nn, *qw = work + L->lwork, *w = qw + L->qwork, *tau = w + n;                  \
+        INT *iwork = (INT*)iw_, *isuppz = iwork + L->liwork;                                                         \
+        const double* c = J->cov + (size_t)i * nn;                                                                   \
+        /* column-major copy of the row-major matrix: a[r + col * n] = C[r][col] */                                  \
+        for (int r = 0; r < n; ++r)                                                                                  \
+            for (int col = 0; col < n; ++col) a[r + (size_t)col * n] = c[(size_t)r * n + col];                       \
+        char jobz = 'V', range = 'A', uplo = 'L';                                                                    \
+        INT nn_ = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = L->lwork, liwork = L->liwork;         \
+        double vl = 0.0, vu = 1.0, abstol = 0.0;                                                                     \
+        ((dsyevr_##SUFFIX)L->syevr)(&jobz, &range, &uplo, &nn_, a, &lda, &vl, &vu, &il, &iu, &abstol, &m, w, z, &ldz, \
+                                    isuppz, work, &lwork, iwork, &liwork, &info);                                    \
+        int status = (int)info;                                                                                      \
+        if (status == 0 && m != n) status = -1000;                                                                   \
+        double* U = J->whiten + (size_t)i * nn;                                                                      \
+        double* Lt = J->tri + (size_t)i * nn;                                                                        \
+        for (int j = 0; j < n; ++j) {                                                                                \
+            J->lam[(size_t)i * n + j] = w[j];                                                                        \
+            const double scale = sqrt(1.0 / w[j]);                                                                   \
+            for (int k = 0; k < n; ++k) U[(size_t)k * n + j] = z[k + (size_t)j * n] * scale;                         \
+        }                                                                                                            \
+        if (status == 0) {                                                                                           \
+            /* the row-major U read as column-major is U^T: factor it in place of a copy */                          \
+            memcpy(Lt, U, sizeof(double) * nn);                                                                      \
+            INT qinfo = 0, qwork = L->qwork;                                                                         \
+            ((dgeqrf_##SUFFIX)L->geqrf)(&nn_, &nn_, Lt, &lda, tau, qw, &qwork, &qinfo);                               \
+            if (qinfo != 0) status = -2000 - (int)qinfo;                                                             \
+            /* R[j][k] (j <= k) sits at Lt[j + k * n] = row-major L[k][j]: zero what lies above the diagonal of L */ \
+            for (int k = 0; k < n; ++k)                                                                              \
+                for (int j = k + 1; j < n; ++j) Lt[(size_t)k * n + j] = 0.0;                                         \
+        } else {                                                                                                     \
+            memset(Lt, 0, sizeof(double) * nn);                                                                      \
+        }                                                                                                            \
+        J->status[i] = status;                                                                                       \
     }
-    if (info == 0) {
-        /* the row-major U read as column-major is U^T: factor it in place of a copy */
-        memcpy(L, U, sizeof(double) * nn);
-        int qinfo = 0, qwork = J->qwork;
-        J->geqrf(&nn_, &nn_, L, &lda, tau, qw, &qwork, &qinfo);
-        if (qinfo != 0) info = -2000 - qinfo;
-        /* R[j][k] (j <= k) sits at L[j + k * n] = row-major L[k][j]: zero what lies above the diagonal of L */
-        for (int k = 0; k < n; ++k)
-            for (int j = k + 1; j < n; ++j) L[(size_t)k * n + j] = 0.0;
-    } else {
-        memset(L, 0, sizeof(double) * nn);
-    }
-    J->status[i] = info;
-}
+
+FACTOR_DEFINE(lp64, int)
+FACTOR_DEFINE(ilp64, int64_t)
 
 /* takes matrices off the job until none are left; scratch memory is the caller's and grows on demand */
 struct factor_scratch {
@@ -175,10 +205,13 @@ struct factor_scratch {
     size_t a_len, iw_len;
 };
 
-static void factor_drain(struct factor_job* J, struct factor_scratch* S) {
+static void factor_drain(struct factor_job* J, struct factor_scratch* S, int who) {
+    /* with two libraries the workers alternate between them: each library serialises part of every BLAS call on a
+     * lock of its own, and two libraries are two locks */
+    const struct factor_lib* L = &J->lib[J->lib[1].syevr ? (who & 1) : 0];
     const size_t nn = (size_t)J->n * J->n;
-    const size_t need_a = 2 * nn + (size_t)J->lwork + (size_t)J->qwork + 2 * (size_t)J->n;
-    const size_t need_i = (size_t)J->liwork + 2 * (size_t)J->n;
+    const size_t need_a = 2 * nn + (size_t)L->lwork + (size_t)L->qwork + 2 * (size_t)J->n;
+    const size_t need_i = 2 * ((size_t)L->liwork + 2 * (size_t)J->n);      /* in ints: room for 64-bit integers */
     if (S->a_len < need_a) {
         free(S->a);
         S->a = (double*)malloc(sizeof(double) * need_a);
@@ -197,7 +230,8 @@ static void factor_drain(struct factor_job* J, struct factor_scratch* S) {
         const int share = __atomic_fetch_add(&J->next, 1, __ATOMIC_RELAXED);
         const long i = (long)J->first + (long)J->step * share;
         if (i >= J->n_mats) break;
-        factor_one(J, (int)i, S->a, S->iw);
+        if (L->ilp64) factor_one_ilp64(J, L, (int)i, S->a, S->iw);
+        else factor_one_lp64(J, L, (int)i, S->a, S->iw);
     }
 }
 
@@ -227,7 +261,7 @@ static void* factor_worker(void* arg) {
         if (me >= pool.wanted) continue;
         struct factor_job* J = pool.job;
         pthread_mutex_unlock(&pool.mu);
-        factor_drain(J, &S);
+        factor_drain(J, &S, me + 1);
         pthread_mutex_lock(&pool.mu);
         if (--pool.running == 0) pthread_cond_signal(&pool.idle);
     }
@@ -258,66 +292,66 @@ static void factor_run(struct factor_job* J, int helpers) {
     ++pool.generation;
     if (helpers > 0) pthread_cond_broadcast(&pool.wake);
     pthread_mutex_unlock(&pool.mu);
-    factor_drain(J, &mine);
+    factor_drain(J, &mine, 0);
     pthread_mutex_lock(&pool.mu);
     while (pool.running > 0) pthread_cond_wait(&pool.idle, &pool.mu);
     pool.job = NULL;
     pthread_mutex_unlock(&pool.mu);
 }
 
-static void* capsule_pointer(PyObject* cap) {
-    if (!PyCapsule_CheckExact(cap)) {
-        PyErr_SetString(PyExc_TypeError, "factor_batch: expected the PyCapsule of a LAPACK routine");
-        return NULL;
+/* a LAPACK routine handed over as the PyCapsule scipy.linalg.cython_lapack exports, or as an integer address */
+static lapack_fn routine_pointer(PyObject* obj) {
+    if (PyCapsule_CheckExact(obj)) return (lapack_fn)PyCapsule_GetPointer(obj, PyCapsule_GetName(obj));
+    if (PyLong_Check(obj)) {
+        void* p = PyLong_AsVoidPtr(obj);
+        if (!p && !PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "factor_batch: null routine address");
+        return (lapack_fn)p;
     }
-    return PyCapsule_GetPointer(cap, PyCapsule_GetName(cap));
+    PyErr_SetString(PyExc_TypeError, "factor_batch: expected the PyCapsule or the address of a LAPACK routine");
+    return NULL;
 }
 
-/* factor_batch(dsyevr, dgeqrf, cov, lam, whiten, tri, status, n_mats, n, first, step, threads) -> None */
+/* factor_batch(dsyevr, dgeqrf, cov, lam, whiten, tri, status, n_mats, n, first, step, threads[, dsyevr2, dgeqrf2, ilp64_2])
+ * -> None.  The optional second pair names the same two routines in a second LAPACK library (ilp64_2: its integer
+ * arguments are 64 bits wide); the worker threads then alternate between the two libraries. */
 static PyObject* factor_batch(PyObject* self, PyObject* args) {
-    PyObject *cap_syevr, *cap_geqrf;
+    PyObject *o_syevr, *o_geqrf, *o_syevr2 = NULL, *o_geqrf2 = NULL;
     Py_buffer cov, lam, whiten, tri, status;
-    int n_mats, n, first, step, threads;
-    if (!PyArg_ParseTuple(args, "OOy*w*w*w*w*iiiii", &cap_syevr, &cap_geqrf, &cov, &lam, &whiten, &tri, &status, &n_mats, &n,
-                          &first, &step, &threads))
+    int n_mats, n, first, step, threads, ilp64_2 = 0;
+    if (!PyArg_ParseTuple(args, "OOy*w*w*w*w*iiiii|OOi", &o_syevr, &o_geqrf, &cov, &lam, &whiten, &tri, &status, &n_mats, &n,
+                          &first, &step, &threads, &o_syevr2, &o_geqrf2, &ilp64_2))
         return NULL;
     PyObject* result = NULL;
-    dsyevr_fn syevr = (dsyevr_fn)capsule_pointer(cap_syevr);
-    dgeqrf_fn geqrf = syevr ? (dgeqrf_fn)capsule_pointer(cap_geqrf) : NULL;
-    if (!syevr || !geqrf) goto done;
-    const Py_ssize_t nn = (Py_ssize_t)n * n;
-    if (n < 1 || n_mats < 0 || first < 0 || step < 1 || cov.len < (Py_ssize_t)(n_mats * nn * sizeof(double)) ||
-        whiten.len < cov.len || tri.len < cov.len || lam.len < (Py_ssize_t)(n_mats * (Py_ssize_t)n * sizeof(double)) ||
-        status.len < (Py_ssize_t)(n_mats * sizeof(int32_t))) {
-        PyErr_SetString(PyExc_ValueError, "factor_batch: buffer sizes do not match n_mats x n x n");
-        goto done;
+    struct factor_job J;
+    memset(&J, 0, sizeof(J));
+    J.lib[0].syevr = routine_pointer(o_syevr);
+    J.lib[0].geqrf = J.lib[0].syevr ? routine_pointer(o_geqrf) : NULL;
+    if (!J.lib[0].syevr || !J.lib[0].geqrf) goto done;
+    if (o_syevr2 && o_syevr2 != Py_None) {
+        J.lib[1].syevr = routine_pointer(o_syevr2);
+        J.lib[1].geqrf = J.lib[1].syevr && o_geqrf2 ? routine_pointer(o_geqrf2) : NULL;
+        J.lib[1].ilp64 = ilp64_2 != 0;
+        if (!J.lib[1].syevr || !J.lib[1].geqrf) goto done;
     }
     {
-        /* workspace queries, as scipy.linalg.eigh (dsyevr_lwork) and numpy.linalg.qr (lwork = -1) make them */
-        char jobz = 'V', range = 'A', uplo = 'L';
-        int nn_ = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = -1, liwork = -1, iwq = 0, isup = 0;
-        double vl = 0.0, vu = 1.0, abstol = 0.0, wq = 0.0, dummy = 0.0;
-        syevr(&jobz, &range, &uplo, &nn_, &dummy, &lda, &vl, &vu, &il, &iu, &abstol, &m, &dummy, &dummy, &ldz, &isup, &wq,
-              &lwork, &iwq, &liwork, &info);
-        if (info != 0) {
-            PyErr_Format(PyExc_RuntimeError, "factor_batch: dsyevr workspace query failed (info %d)", info);
+        const Py_ssize_t nn = (Py_ssize_t)n * n;
+        if (n < 1 || n_mats < 0 || first < 0 || step < 1 || cov.len < (Py_ssize_t)(n_mats * nn * sizeof(double)) ||
+            whiten.len < cov.len || tri.len < cov.len || lam.len < (Py_ssize_t)(n_mats * (Py_ssize_t)n * sizeof(double)) ||
+            status.len < (Py_ssize_t)(n_mats * sizeof(int32_t))) {
+            PyErr_SetString(PyExc_ValueError, "factor_batch: buffer sizes do not match n_mats x n x n");
             goto done;
         }
-        int q_lwork = -1, qinfo = 0;
-        double qq = 0.0;
-        geqrf(&nn_, &nn_, &dummy, &lda, &dummy, &qq, &q_lwork, &qinfo);
-        if (qinfo != 0) {
-            PyErr_Format(PyExc_RuntimeError, "factor_batch: dgeqrf workspace query failed (info %d)", qinfo);
-            goto done;
+        for (int k = 0; k < 2 && J.lib[k].syevr; ++k) {
+            const int info = J.lib[k].ilp64 ? factor_query_ilp64(&J.lib[k], n) : factor_query_lp64(&J.lib[k], n);
+            if (info != 0) {
+                PyErr_Format(PyExc_RuntimeError, "factor_batch: workspace query of library %d failed (info %d)", k, info);
+                goto done;
+            }
         }
         int count = (n_mats - first + step - 1) / step;
         if (count < 0) count = 0;
         if (threads < 1) threads = 1;
         if (threads > count) threads = count > 0 ? count : 1;
-        struct factor_job J;
-        memset(&J, 0, sizeof(J));
-        J.syevr = syevr;
-        J.geqrf = geqrf;
         J.cov = (const double*)cov.buf;
         J.lam = (double*)lam.buf;
         J.whiten = (double*)whiten.buf;
@@ -327,11 +361,8 @@ static PyObject* factor_batch(PyObject* self, PyObject* args) {
         J.n_mats = n_mats;
         J.first = first;
         J.step = step;
-        J.lwork = (int)wq > 1 ? (int)wq : 1;
-        J.liwork = iwq > 1 ? iwq : 1;
-        J.qwork = (int)qq > n ? (int)qq : n;
-        /* the pool and the caller's scratch are process-wide: the GIL is kept until the job has been handed over
-         * and is released while the calling thread works on its share (factor_run) */
+        /* the pool and the caller's scratch are process-wide: one call at a time; the GIL is released while the
+         * calling thread waits for its turn and works on its share */
         Py_BEGIN_ALLOW_THREADS
         pthread_mutex_lock(&call_mu);
         factor_run(&J, threads - 1);

@@ -120,6 +120,56 @@ def _host_threads() -> int:
 
 
 _factor_executor = None
+_second_lapack = False          # False: not looked for yet; None: there is none (or it failed its check)
+
+
+def _find_second_lapack():
+    """(dsyevr address, dgeqrf address, 1) of the ILP64 OpenBLAS build that NumPy's wheel brings along, if it is there
+    and factors test matrices to the very bits of SciPy's library; else None.
+
+    Why a second library at all: inside one process the factorisation threads stop scaling at about four, whatever
+    the machine (sixteen single-threaded PROCESSES factor the same batch four times faster than sixteen threads),
+    because OpenBLAS takes a library-wide lock around the work buffer of nearly every BLAS call.  A second copy of
+    the library is a second lock: with the worker threads alternating between the two, eight threads do what four
+    did per library.  Both copies are builds of the same OpenBLAS; that they round alike is not taken on trust but
+    checked here once per process, and any difference (or a missing symbol) leaves the second copy unused."""
+    global _second_lapack
+    if _second_lapack is not False:
+        return _second_lapack
+    _second_lapack = None
+    try:
+        import ctypes
+        import glob
+
+        import scipy.linalg.cython_lapack as lapack
+
+        from . import _lsr_pyhelper as H
+
+        folder = os.path.join(os.path.dirname(os.path.dirname(np.__file__)), "numpy.libs")
+        for path in sorted(glob.glob(os.path.join(folder, "libscipy_openblas64_*.so"))):
+            lib = ctypes.CDLL(path)                          # NumPy has it loaded already: this only takes a handle
+            second = (ctypes.cast(lib.scipy_dsyevr_64_, ctypes.c_void_p).value,
+                      ctypes.cast(lib.scipy_dgeqrf_64_, ctypes.c_void_p).value, 1)
+            caps = lapack.__pyx_capi__
+            rng = np.random.default_rng(7)
+            S, d = 12, DIM_CHECK
+            a = rng.standard_normal((S, d, d)) * rng.uniform(0.2, 20, size=(S, 1, 1))
+            cov = np.ascontiguousarray((a @ a.transpose(0, 2, 1) / d + 1e-3 * np.eye(d)).astype(np.float32), dtype=np.float64)
+            out = []
+            for extra in ((), second):
+                lam, u, l, st = np.zeros((S, d)), np.zeros((S, d, d)), np.zeros((S, d, d)), np.zeros(S, np.int32)
+                # two threads: thread 0 uses the first library, thread 1 the second one when it is given
+                H.factor_batch(caps["dsyevr"], caps["dgeqrf"], cov, lam, u, l, st, S, d, 0, 1, 2, *extra)
+                out.append((lam, u, l, st))
+            if all(np.array_equal(x, y) for x, y in zip(*out)) and not out[1][3].any():
+                _second_lapack = second
+            break
+    except Exception:                                        # no such library, other symbol names, ...: one library
+        _second_lapack = None
+    return _second_lapack
+
+
+DIM_CHECK = 39
 
 
 def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Optional[int] = None,
@@ -154,8 +204,12 @@ def factor_covariances(means: np.ndarray, covariances: np.ndarray, threads: Opti
     # a matrix with NaN or infinite entries never reaches LAPACK (scipy.linalg.eigh(check_finite=True))
     safe = cov if finite.all() else np.where(finite[:, None, None], cov, np.eye(d))
     caps = lapack.__pyx_capi__
+    n_own = len(range(first, S, step))
+    second = _find_second_lapack() if n_own >= 8 and (threads is None or threads >= 4) else None
+    if threads is None:                       # one library feeds about four threads (see _find_second_lapack)
+        threads = min(_host_threads(), 8 if second else 6)
     args = (caps["dsyevr"], caps["dgeqrf"], np.ascontiguousarray(safe), lam, whiten, tri, status, S, d, first, step,
-            threads or min(_host_threads(), 6))
+            threads) + (second or ())
     if meanwhile is None:
         H.factor_batch(*args)
     else:
