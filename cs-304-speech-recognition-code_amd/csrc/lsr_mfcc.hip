@@ -63,8 +63,9 @@ __device__ __forceinline__ void dft4(const cplx a, const cplx b, const cplx c, c
 // inside the clip (lo | hi << 16); the rest of the window is the zero padding.
 __global__ void lsr_frame_index_kernel(const int64_t* __restrict__ frame_off, const int64_t* __restrict__ sample_off,
                                        int64_t total_frames, int32_t* __restrict__ frame_utt,
-                                       int4* __restrict__ frame_info) {
+                                       int4* __restrict__ frame_info, unsigned int* __restrict__ uttmax) {
     const int b = blockIdx.x;
+    if (threadIdx.x == 0) uttmax[b] = 0u;               // the utterance maximum starts at zero (one block per utterance)
     const int64_t lo = frame_off[b];
     int64_t hi = frame_off[b + 1];
     if (hi > total_frames) hi = total_frames;           // the tables hold total_frames entries whatever the offsets say
@@ -604,11 +605,9 @@ int lsr_launch_mfcc_ws(lsr_ctx* ctx, const void* audio_d, int audio_is_i16, cons
     int32_t* frame_utt = ws.frame_utt;
     float* mel = ws.mel;
     unsigned int* uttmax = ws.uttmax;
-    LSR_HIP_CHECK(ctx, hipMemsetAsync(uttmax, 0, (size_t)n_utts * sizeof(unsigned int), ctx->stream));
-
     lsr_prof_begin(ctx, LSR_K_FRAME_INDEX);
     hipLaunchKernelGGL(lsr_frame_index_kernel, dim3(n_utts), dim3(256), 0, ctx->stream, frame_off_d, sample_off_d,
-                       total_frames, frame_utt, frame_info);
+                       total_frames, frame_utt, frame_info, uttmax);
     lsr_prof_end(ctx);
     LSR_LAUNCH_CHECK(ctx, "lsr_frame_index_kernel");
 
