@@ -503,7 +503,8 @@ extern "C" int lsr_emission_batch(lsr_ctx* ctx, const float* feats_d, int64_t to
 }
 
 static size_t ll_bytes(const lsr_ctx* ctx, int64_t total_frames) {
-    return (size_t)((total_frames + 63) / 64 * 64) * lsr_ctx_ll_stride(ctx) * sizeof(float);
+    // whole tiles of 64 frames, and one more: the decoder requests scores up to fifteen rows past an utterance's end
+    return (size_t)((total_frames + 63) / 64 * 64 + 64) * lsr_ctx_ll_stride(ctx) * sizeof(float);
 }
 
 extern "C" int lsr_ll_stride(const lsr_ctx* ctx) { return ctx ? lsr_ctx_ll_stride(ctx) : LSR_LL_STRIDE; }
@@ -572,7 +573,8 @@ int lsr_reserve_recognize(lsr_ctx* ctx, int n_utts, int64_t total_frames) {
     if ((rc = lsr_reserve(ctx, &ctx->ws_frame_info, (size_t)total_frames * 16, "frame records"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_feats, (size_t)total_frames * LSR_DIM * sizeof(float), "features"))) return rc;
     if ((rc = lsr_reserve(ctx, &ctx->ws_ll, ll_bytes(ctx, total_frames), "emission scores"))) return rc;
-    return lsr_reserve(ctx, &ctx->ws_tracer, (size_t)total_frames * (ctx->g_states > 64 ? 128 : 64), "back-pointers");
+    return lsr_reserve(ctx, &ctx->ws_tracer,
+                       ctx->g_states > 64 ? (size_t)total_frames * 128 : LSR_TRACER_BYTES(total_frames, n_utts), "back-pointers");
 }
 
 static int recognize_any(lsr_ctx* ctx, const void* audio_d, int is_i16, const int64_t* sample_off_d,

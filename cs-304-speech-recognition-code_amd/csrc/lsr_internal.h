@@ -15,6 +15,9 @@
 #define LSR_TRI_SLOTS 56     // blocks per state of a triangular whitening matrix (55) rounded up
 #define LSR_KSTEPS 10        // LSR_KPAD / 4
 #define LSR_GRAPH_STRIDE 128 // row stride of the loop-graph tables (band, flags, word maps)
+// bytes of the back-pointer table of the one-wavefront Viterbi kernel (graphs / chains of at most 64 states): one
+// 256-byte group per four frames, every utterance starting a group of its own
+#define LSR_TRACER_BYTES(total_frames, n_utts) ((((size_t)(total_frames) >> 2) + (size_t)(n_utts)) * 256)
 
 struct lsr_buffer {
     void* ptr = nullptr;

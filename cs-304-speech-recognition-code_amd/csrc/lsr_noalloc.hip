@@ -19,7 +19,7 @@
 // byte offsets of the parts (each 256-byte aligned)
 #define NA_OFF_LL 0
 #define NA_OFF_TRACER (NA_OFF_LL + NA_ALIGN((size_t)LSR_NOALLOC_MAX_FRAMES * LSR_LL_STRIDE * 4))
-#define NA_OFF_MEL (NA_OFF_TRACER + NA_ALIGN((size_t)LSR_NOALLOC_MAX_FRAMES * 64))
+#define NA_OFF_MEL (NA_OFF_TRACER + NA_ALIGN(LSR_TRACER_BYTES(LSR_NOALLOC_MAX_FRAMES, LSR_NOALLOC_MAX_UTTS)))
 #define NA_OFF_FEATS (NA_OFF_MEL + NA_ALIGN((size_t)LSR_NOALLOC_MAX_FRAMES * LSR_N_MELS * 4))
 #define NA_OFF_INFO (NA_OFF_FEATS + NA_ALIGN((size_t)LSR_NOALLOC_MAX_FRAMES * LSR_DIM * 4))
 #define NA_OFF_FUTT (NA_OFF_INFO + NA_ALIGN((size_t)LSR_NOALLOC_MAX_FRAMES * 16))
