@@ -217,7 +217,7 @@ int lsr_download_host(lsr_ctx* ctx, const void* src_d, int64_t bytes, void* dst,
 /* lsr_recognize_batch (float32 audio) for callers that cannot allocate device memory: code under
  * HIP stream capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
  * in the reference.  Same arguments, same kernels and bit-identical outputs; every intermediate
- * buffer lives in one static device array of about 41 MiB per GPU (held until the process ends)
+ * buffer lives in one static device array of about 42 MiB per GPU (held until the process ends)
  * instead of the context's growing workspace, and the call performs no hipMalloc / hipFree.
  * Limits: n_utts <= LSR_NOALLOC_MAX_UTTS, total_frames <= LSR_NOALLOC_MAX_FRAMES and a loop graph of
  * at most 64 states (LSR_ERR_LIMIT beyond); profiling must be off (LSR_ERR_STATE).  All calls on one GPU share the
