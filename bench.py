@@ -209,19 +209,25 @@ def run_other(eng, torch, config_id, sigs, truth, steps, warmup, barrier=None):
     for _ in range(warmup):
         step()
     sync()
-    eng.profile_reset()
-    eng.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    # per-kernel HIP-event times from a few steps of their own (event records inside a sub-millisecond step would be
+    # a visible part of it)
+    k_steps = max(3, min(steps, 10))
+    eng.profile_reset()
+    eng.profile_enable(True)
+    for _ in range(k_steps):
+        step()
+    sync()
     eng.profile_enable(False)
     kernels = {}
     for k in ("frame_index", "mel_power", "mfcc_finish", "emission", "viterbi", "stats"):
         ms, n = eng.profile_get(k)
         if n:
-            kernels[k] = round(ms / steps, 4)          # per step (a step may launch a kernel more than once)
+            kernels[k] = round(ms / k_steps, 4)        # per step (a step may launch a kernel more than once)
     rec = {"config": config_id, "workload": cfg["what"] if ab.n == cfg["utts"] else
            f"{cfg['what']} -- run on {ab.n} clips of that kind", "utterances": ab.n, "frames": int(ab.total_frames),
            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "value": ab.n * steps / elapsed,
@@ -367,13 +373,14 @@ def main():
             return float(t.item())
         return x
 
-    def timed(step, steps, warmup, profile=False):
+    def timed(step, steps, warmup, profile=None):
+        """profile: names of the kernels whose launches carry HIP events inside the timed region."""
         for _ in range(warmup):
             step()
         barrier()
         if profile:
             eng.profile_reset()
-            eng.profile_enable(True)
+            eng.profile_enable(True, only=profile)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -383,13 +390,20 @@ def main():
             eng.profile_enable(False)
         return max_over_ranks(elapsed)
 
+    # Headline: the timed steps carry HIP events around the roofline kernel only (two event records per launch cost a few
+    # microseconds each, which a 0.7 ms step of a small shard would feel); the other kernels are timed with events in a
+    # few steps of their own right after, outside the timed region.
     step, state = make_step(ab, n_total)
-    elapsed = timed(step, args.steps, args.warmup, profile=True)
+    elapsed = timed(step, args.steps, args.warmup, profile=("emission",))
     out = state["out"]
-    kernels = {}                      # HIP-event times of the headline steps (later measurements reset the counters)
-    for k in ("frame_index", "mel_power", "mfcc_finish", "emission", "viterbi"):
+    kernels = {}
+    ms, n = eng.profile_get("emission")
+    kernels["emission"] = {"ms_per_launch": ms / max(n, 1), "launches": n, "measured": "inside the timed steps"}
+    side_steps = max(3, min(args.steps, 10))
+    timed(step, side_steps, 0, profile=("frame_index", "mel_power", "mfcc_finish", "emission", "viterbi"))
+    for k in ("frame_index", "mel_power", "mfcc_finish", "viterbi"):
         ms, n = eng.profile_get(k)
-        kernels[k] = {"ms_per_launch": ms / max(n, 1), "launches": n}
+        kernels[k] = {"ms_per_launch": ms / max(n, 1), "launches": n, "measured": f"{side_steps} steps after the timed ones"}
 
     # results of the last step: strings, accuracy vs the generating strings and vs the CPU path
     strings = records_to_strings(out[2].cpu().numpy(), out[3].cpu().numpy(), names)

@@ -43,7 +43,8 @@ static hipEvent_t take_event(lsr_ctx* ctx) {
 }
 
 void lsr_prof_begin(lsr_ctx* ctx, int kernel) {
-    if (!ctx->profiling) return;
+    ctx->prof_open = false;
+    if (!ctx->profiling || !(ctx->profile_mask & (1 | LSR_PROFILE_ONLY(kernel)))) return;
     lsr_ctx::pending p;
     p.kernel = kernel;
     p.start = take_event(ctx);
@@ -51,10 +52,12 @@ void lsr_prof_begin(lsr_ctx* ctx, int kernel) {
     if (!p.start || !p.stop) return;
     (void)hipEventRecord(p.start, ctx->stream);
     ctx->pend.push_back(p);
+    ctx->prof_open = true;
 }
 
 void lsr_prof_end(lsr_ctx* ctx) {
-    if (!ctx->profiling || ctx->pend.empty()) return;
+    if (!ctx->prof_open || ctx->pend.empty()) return;
+    ctx->prof_open = false;
     (void)hipEventRecord(ctx->pend.back().stop, ctx->stream);
 }
 
@@ -74,6 +77,7 @@ static void drain_profile(lsr_ctx* ctx) {
 extern "C" int lsr_profile_enable(lsr_ctx* ctx, int on) {
     if (!ctx) return LSR_ERR_ARG;
     ctx->profiling = on != 0;
+    ctx->profile_mask = on;
     return LSR_OK;
 }
 

@@ -80,6 +80,8 @@ struct lsr_ctx {
 
     // profiling
     bool profiling = false;
+    int profile_mask = 0;            // argument of lsr_profile_enable: bit 0 = every kernel, bit 1 + k = kernel k
+    bool prof_open = false;          // lsr_prof_begin recorded a start event that lsr_prof_end has to close
     struct pending { int kernel; hipEvent_t start, stop; };
     std::vector<pending> pend;
     std::vector<hipEvent_t> event_pool;

@@ -239,8 +239,12 @@ class Engine:
         return self.torch.empty(shape, dtype=dtype, device=self.device)
 
     # -- profiling --------------------------------------------------------------------------------
-    def profile_enable(self, on: bool) -> None:
-        self._check(self.lib.lsr_profile_enable(self.ctx, 1 if on else 0))
+    def profile_enable(self, on: bool, only: Optional[Sequence[str]] = None) -> None:
+        """Event pairs around every kernel launch, or around the launches of the kernels named in ``only``."""
+        mode = 0
+        if on:
+            mode = 1 if only is None else sum(2 << KERNEL_IDS[k] for k in set(only))
+        self._check(self.lib.lsr_profile_enable(self.ctx, mode))
 
     def profile_reset(self) -> None:
         self._check(self.lib.lsr_profile_reset(self.ctx))

@@ -73,7 +73,10 @@ int lsr_set_stream(lsr_ctx* ctx, void* hip_stream);   /* hipStream_t; NULL = nul
 int lsr_synchronize(lsr_ctx* ctx);                    /* blocks until the stream is idle  */
 
 /* Per-kernel device time, measured with HIP events on the context's stream around every
- * launch while enabled (adds two event records per launch).  lsr_profile_get synchronises. */
+ * launch while enabled (adds two event records per launch).  on: 0 = off, 1 = every kernel,
+ * LSR_PROFILE_ONLY(k) (may be or-ed) = only the launches of kernel id k, so that a timed region can carry the
+ * events of one kernel without paying for those of the others.  lsr_profile_get synchronises. */
+#define LSR_PROFILE_ONLY(kernel_id) (2 << (kernel_id))
 int lsr_profile_enable(lsr_ctx* ctx, int on);
 int lsr_profile_reset(lsr_ctx* ctx);
 int lsr_profile_get(lsr_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);

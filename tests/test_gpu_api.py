@@ -96,6 +96,34 @@ def test_isolated_classifier_on_word_clips(words):
     assert np.mean([a == b for a, b in zip(got, labels)]) > 0.9
 
 
+def test_kernel_timing_can_be_limited_to_named_kernels(words):
+    """lsr_profile_enable(LSR_PROFILE_ONLY(k)): only the launches of kernel k carry event pairs."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, _native, synthetic
+
+    eng = _native.get_engine()
+    inf = HiddenMarkovModelInference.from_models([words[lab] for lab in synthetic.LOOP_ORDER])
+    inf._log_transition_probability_between_words = -100
+    inf._bind()
+    sigs, truth = synthetic.batch(3, 8, 2, start=8300)
+    ab = eng.audio_batch(sigs)
+    try:
+        eng.profile_reset()
+        eng.profile_enable(True, only=("emission", "viterbi"))
+        for _ in range(3):
+            eng.recognize(ab, want_paths=False, label_cap=16)
+        counts = {k: eng.profile_get(k) for k in ("frame_index", "mel_power", "mfcc_finish", "emission", "viterbi")}
+        assert counts["emission"][1] == 3 and counts["viterbi"][1] == 3
+        assert counts["emission"][0] > 0 and counts["viterbi"][0] > 0
+        assert counts["frame_index"][1] == counts["mel_power"][1] == counts["mfcc_finish"][1] == 0
+        eng.profile_reset()
+        eng.profile_enable(True)
+        eng.recognize(ab, want_paths=False, label_cap=16)
+        assert all(eng.profile_get(k)[1] == 1 for k in counts)
+    finally:
+        eng.profile_enable(False)
+        eng.profile_reset()
+
+
 def test_c_abi_rejects_bad_arguments():
     from loe_speech_recognition_amd import _native
 
