@@ -140,6 +140,56 @@ def test_random_alignment_chain(seed):
         assert np.array_equal(out[i][1], path), (seed, i)
 
 
+def test_every_length_across_the_kernel_boundaries():
+    """Utterances of 1 .. 140 frames in one batch: the recursion's single-frame head ((T - 1) % 8 frames), the
+    four-frame back-pointer groups and the 64-frame blocks of the back-trace all change shape with T."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, HiddenMarkovModelMultiWord, _native
+
+    rng = np.random.default_rng(4242)
+    words = _graph(rng, 60, tied=True)
+    inf = HiddenMarkovModelInference.from_models([trainable(*w) for w in words])
+    ltp, gauss, bounds = O.stack_models([O.WordModelRef(*w) for w in words])
+    S = bounds.num_states
+    band = O.band_from_ltp(ltp, S, [bounds.find_lower(s) for s in range(S)])
+    xs = [(1.5 * rng.standard_normal((t, 39))).astype(np.float32) for t in range(1, 141)]
+    eng = _native.get_engine()
+    for between in (-3, np.float64(-7.5)):
+        inf._log_transition_probability_between_words = between
+        vit = inf.viterbi_batch(xs)
+        strings = [None] + inf.predict_batch(xs[1:])              # a one-frame utterance has no labels (the reference raises)
+        inf._bind()
+        ll = eng.emission(eng.feature_batch(xs)).cpu().numpy()
+        t0 = 0
+        for i, x in enumerate(xs):
+            score, path = O.viterbi_loop_fast(ll[t0:t0 + x.shape[0], :S], band, bounds.lower, bounds.upper, between)
+            t0 += x.shape[0]
+            assert vit[i][0] == score, (between, i)
+            assert np.array_equal(vit[i][1], path), (between, i)
+            if i:
+                assert strings[i] == "".join(bounds.get_labels(path)), (between, i)
+    # the same lengths through the chain form (a chain of the first words, at most 64 states)
+    by_label = {w[0]: w for w in words}
+    chain, n_states = "", 0
+    for w in words:
+        if n_states + w[1].shape[0] > 40:
+            break
+        chain += w[0]
+        n_states += w[1].shape[0]
+    hmm = HiddenMarkovModelMultiWord.from_labels(chain, {lab: trainable(*w) for lab, w in by_label.items()})
+    cltp, _, _ = O.stack_models([O.WordModelRef(*by_label[lab]) for lab in chain])
+    cband = O.band_from_ltp(cltp, n_states)
+    out = hmm.predict_batch(xs)
+    token, arrays = hmm._device_model()
+    eng.set_model(token, *arrays)
+    ll = eng.emission(eng.feature_batch(xs)).cpu().numpy()
+    t0 = 0
+    for i, x in enumerate(xs):
+        score, path, _ = O.viterbi_chain_fast(ll[t0:t0 + x.shape[0], :n_states], cband)
+        t0 += x.shape[0]
+        assert out[i][0] == score or (np.isnan(out[i][0]) and np.isnan(score)), i
+        assert np.array_equal(out[i][1], path), i
+
+
 def test_utterance_longer_than_64k_frames_and_the_limit():
     """One utterance of 70 000 frames (its path needs more than 64 KiB of LDS, a size the launcher has to ask for)
     next to a short one; beyond the LDS of a compute unit the decoder refuses with a clear error."""
