@@ -51,3 +51,15 @@ def test_three_wavefronts_per_simd_without_spills(tmp_path, source, pattern, max
         assert r["ScratchSize"] == 0, (name, r)
         assert r["VGPRs"] + r.get("AGPRs", 0) <= max_vgprs, (name, r)
         assert r["Occupancy"] >= 3, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_viterbi_wavefronts_stay_at_full_occupancy(tmp_path):
+    """The one-wavefront-per-utterance decoder holds 32 registers of back-pointer groups during the back-trace; with
+    more than 64 registers fewer than eight wavefronts fit a SIMD and the streaming regime of full batches slows down."""
+    kernels = {k: v for k, v in _resources("lsr_viterbi.hip", tmp_path).items() if "lsr_viterbi_kernelILi" in k}
+    assert len(kernels) == 6, sorted(kernels)          # three recursions x two row strides
+    for name, r in kernels.items():
+        assert r["ScratchSize"] == 0, (name, r)
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 64, (name, r)
+        assert r["Occupancy"] >= 8, (name, r)
