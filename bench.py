@@ -158,7 +158,12 @@ def _setup(args):
     backend = os.environ.get("LSR_DIST_BACKEND", "nccl")
     dev = local % torch.cuda.device_count()          # more ranks than GPUs only in gloo rehearsals
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or getattr(args, "exchange_at_one", False):
+        if world == 1:                                # one-rank group on one GPU: exercises the exchange code path
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
@@ -288,6 +293,8 @@ def main():
                     help="skip the bounded runs of configs 2, 4 and 5 that a default one-GPU run appends")
     ap.add_argument("--comm", choices=("torch", "capi"), default="torch",
                     help="collectives through torch.distributed (default) or through the library's own RCCL entry points")
+    ap.add_argument("--exchange-at-one", action="store_true",
+                    help="testing aid: run the exchange step with a one-rank process group on a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host -> device pipeline measurement")
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
@@ -343,6 +350,8 @@ def main():
     upload_s = time.perf_counter() - t0
     label_cap = 16
 
+    exchange = world > 1 or args.exchange_at_one      # the step ends with the all-gather of the label records
+
     def make_step(batch, n_global):
         out = (eng.empty((batch.n,), torch.float32), None, eng.empty((batch.n, label_cap), torch.uint8),
                eng.empty((batch.n,), torch.int32))
@@ -350,9 +359,12 @@ def main():
 
         def step():
             eng.recognize(batch, want_paths=False, label_cap=label_cap, out=out)
-            if world > 1:
+            if exchange:
                 # the exchange step of the path: every rank ends up with the label records (word ids + count)
-                # of the whole job in global utterance order, one all-gather of 20-byte records per step
+                # of the whole job in global utterance order, one all-gather of 20-byte records per step, in line
+                # on the compute stream (moving it to a side stream so that it overlaps the next step's kernels was
+                # measured with a one-rank group: the cross-stream events cost more than the gather, 0.69 against
+                # 0.65 ms per step of 1 250 clips)
                 if comm is not None:
                     state["records"] = comm.gather_label_records(out[2], out[3], n_global)
                 elif backend == "nccl":
@@ -362,12 +374,12 @@ def main():
         return step, state
 
     def barrier():
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world > 1:
+        if exchange:
             t = torch.tensor([x], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -408,7 +420,7 @@ def main():
     # results of the last step: strings, accuracy vs the generating strings and vs the CPU path
     strings = records_to_strings(out[2].cpu().numpy(), out[3].cpu().numpy(), names)
     n_right = sum(a == b for a, b in zip(strings, truth))
-    if world > 1:
+    if exchange:
         t = torch.tensor([n_right], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n_right = float(t.item())
@@ -503,7 +515,7 @@ def main():
                                    f"between=-100, {args.scaling} scaling",
                        "utterances_per_gpu": ab.n, "frames_per_gpu": int(total_frames),
                        "audio_mb_per_gpu": round(total_samples * 4 / 1e6, 1),
-                       "parallelism": f"utterance-sharded x{world}" + (", all-gather of label records" if world > 1 else "")},
+                       "parallelism": f"utterance-sharded x{world}" + (", all-gather of label records" if exchange else "")},
             "roofline": {"bound": "mfma", "kernel": "lsr_emission_kernel", "achieved": flops_exec / em_s / 1e12,
                          "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops_exec / em_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
@@ -548,7 +560,7 @@ def main():
         print(json.dumps(line))
     if comm is not None:
         comm.close()
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

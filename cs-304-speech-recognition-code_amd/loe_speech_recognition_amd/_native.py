@@ -228,6 +228,13 @@ class Engine:
     def synchronize(self) -> None:
         self._check(self.lib.lsr_synchronize(self.ctx))
 
+    def use_stream(self, stream=None) -> None:
+        """Launch the library's kernels on ``stream`` (a torch.cuda.Stream; None: torch's current stream) from now
+        on.  Ordering against work already queued on the previous stream is the caller's business (events)."""
+        if stream is None:
+            stream = self.torch.cuda.current_stream(self.device)
+        self._check(self.lib.lsr_set_stream(self.ctx, c_void_p(stream.cuda_stream)))
+
     @staticmethod
     def _ptr(t) -> c_void_p:
         return c_void_p(0) if t is None else c_void_p(t.data_ptr())
