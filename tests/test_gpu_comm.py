@@ -1,8 +1,6 @@
 """The multi-GPU exchange steps behind the C ABI on the one GPU a test box has: the device pack / unpack kernels
 against the host functions for simulated multi-rank layouts, and lsr_comm_init / lsr_allgather_labels /
 lsr_allreduce_stats on a one-rank RCCL communicator (more ranks need more GPUs: RCCL refuses two ranks on one device)."""
-import os
-
 import numpy as np
 import pytest
 
@@ -69,22 +67,3 @@ def test_one_rank_communicator_gather_and_reduce():
         comm.close()
     with pytest.raises(_native.NativeError):              # no communicator any more
         eng._check(eng.lib.lsr_allreduce_stats(eng.ctx, eng._ptr(d), 4))
-
-
-def test_bench_exchange_step_with_a_one_rank_rccl_group():
-    """bench.py's N > 1 step (decode, then the all-gather of the label records through torch.distributed over RCCL)
-    on this one GPU with a one-rank process group: the records that come back are the rank's own output and the
-    line reports the exchange.  Runs in a process of its own (a process group belongs to its process)."""
-    import json
-    import subprocess
-    import sys
-
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
-    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--utts", "96", "--steps", "3", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-h2d", "--no-other-configs", "--exchange-at-one"],
-                         capture_output=True, text=True, timeout=300, env=env)
-    assert run.returncode == 0, run.stderr[-2000:]
-    line = json.loads(run.stdout.strip().splitlines()[-1])
-    assert "all-gather of label records" in line["config"]["parallelism"]
-    assert line["seq_accuracy_vs_truth"] == 1.0 and line["n_gpus"] == 1 and line["value"] > 0
