@@ -72,6 +72,8 @@ struct lsr_ctx {
     // workspace
     lsr_buffer ws_frame_utt, ws_mel, ws_uttmax, ws_feats, ws_ll, ws_tracer, ws_slab, ws_sep, ws_frame_info, ws_sort, ws_mask;
 
+    int host_check_finite = 1;       // lsr_host_check_finite: bit 0 float32 audio of lsr_recognize_host, bit 1 4-byte arrays of lsr_upload_host
+
     // host -> device pipeline of lsr_recognize_host (created on first use)
     struct lsr_pipeline* pipeline = nullptr;
 

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -96,32 +97,55 @@ struct lsr_pipeline {
 // Copy used by the packing threads.  A clip is read once and the pinned staging chunk is only read back by the DMA
 // engine, so the stores go around the cache (non-temporal): memcpy's ordinary stores first read every destination
 // line, three memory transfers per byte instead of two (16 threads of a pool host pack 128 GB/s this way, 68 GB/s
-// with memcpy).
-static void copy_streaming(void* dst, const void* src, size_t n) {
+// with memcpy).  With check_f32 the bytes are float32 values and the return value tells whether all of them are
+// finite (the test rides on the copy: the data passes through registers anyway).
+static bool copy_streaming(void* dst, const void* src, size_t n, bool check_f32) {
+    unsigned char* d = (unsigned char*)dst;
+    const unsigned char* s = (const unsigned char*)src;
+    auto finite_scalar = [](const unsigned char* p, size_t bytes) {
+        bool ok = true;
+        for (size_t i = 0; i + 4 <= bytes; i += 4) {
+            uint32_t u;
+            memcpy(&u, p + i, 4);
+            ok = ok && (u & 0x7f800000u) != 0x7f800000u;
+        }
+        return ok;
+    };
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
     typedef long long v2ll __attribute__((vector_size(16)));
     typedef long long v2ll_u __attribute__((vector_size(16), aligned(1)));
-    unsigned char* d = (unsigned char*)dst;
-    const unsigned char* s = (const unsigned char*)src;
+    typedef unsigned int v4u __attribute__((vector_size(16)));
     if (n < 512) {
         memcpy(d, s, n);
-        return;
+        return !check_f32 || finite_scalar(s, n);
     }
-    const size_t head = (16 - ((uintptr_t)d & 15)) & 15;      // non-temporal stores need 16-byte aligned addresses
+    bool ok = true;
+    size_t head = (16 - ((uintptr_t)d & 15)) & 15;            // non-temporal stores need 16-byte aligned addresses
+    if (check_f32) head = (head + 3) & ~(size_t)3;            // whole values (float arrays start on 4-byte boundaries,
+                                                              // so a 16-byte boundary is a whole number of values away)
     memcpy(d, s, head);
+    if (check_f32) ok = finite_scalar(s, head);
     d += head, s += head, n -= head;
     const size_t blocks = n / 64;
+    const v4u expo = {0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u};
+    v4u bad = {0u, 0u, 0u, 0u};                               // lanes that saw an all-ones exponent (infinity or NaN)
     for (size_t i = 0; i < blocks; ++i, s += 64, d += 64) {
         const v2ll a = *(const v2ll_u*)s, b = *(const v2ll_u*)(s + 16), c = *(const v2ll_u*)(s + 32), e = *(const v2ll_u*)(s + 48);
+        if (check_f32)
+            bad |= (v4u)((((v4u)a & expo) == expo) | (((v4u)b & expo) == expo) | (((v4u)c & expo) == expo) |
+                         (((v4u)e & expo) == expo));
         __builtin_nontemporal_store(a, (v2ll*)d);
         __builtin_nontemporal_store(b, (v2ll*)(d + 16));
         __builtin_nontemporal_store(c, (v2ll*)(d + 32));
         __builtin_nontemporal_store(e, (v2ll*)(d + 48));
     }
     memcpy(d, s, n - blocks * 64);
+    if (check_f32) ok = ok && !(bad[0] | bad[1] | bad[2] | bad[3]) && finite_scalar(s, n - blocks * 64);
     __builtin_ia32_sfence();      // the stores are globally visible before the chunk is handed to the copy engine
+    return ok;
 #else
-    memcpy(dst, src, n);
+    memcpy(d, s, n);
+    return !check_f32 || finite_scalar(s, n);
 #endif
 }
 
@@ -322,10 +346,18 @@ extern "C" int lsr_recognize_host(lsr_ctx* ctx, const void* const* clips, const 
             while (b < nb && soff[b] < goal) ++b;
             cut[t] = t == tasks ? nb : b;
         }
+        const bool check = !audio_is_i16 && (ctx->host_check_finite & 1);
+        std::atomic<int> bad_clip(INT32_MAX);              // lowest clip of the chunk with a non-finite sample
         p->pool->parallel_for(tasks, [&](int t) {
             for (int i = cut[t]; i < cut[t + 1]; ++i)
-                copy_streaming(stage + (size_t)soff[i] * esz, clips[b0 + i], (size_t)n_samples[b0 + i] * esz);
+                if (!copy_streaming(stage + (size_t)soff[i] * esz, clips[b0 + i], (size_t)n_samples[b0 + i] * esz, check)) {
+                    int seen = bad_clip.load();
+                    while (b0 + i < seen && !bad_clip.compare_exchange_weak(seen, b0 + i)) {}
+                }
         });
+        if (bad_clip.load() != INT32_MAX)
+            return lsr_fail(ctx, LSR_ERR_ARG, "lsr_recognize_host: clip %d holds a non-finite sample (audio must be finite)",
+                            bad_clip.load());
         const size_t total_bytes = audio_bytes + 2 * (size_t)(nb + 1) * sizeof(int64_t);
         const double t2 = pipe_now();
         LSR_HIP_CHECK(ctx, hipMemcpyAsync(s.device, s.pinned, total_bytes, hipMemcpyHostToDevice, p->copy_stream));
@@ -357,6 +389,13 @@ extern "C" int lsr_recognize_host(lsr_ctx* ctx, const void* const* clips, const 
     memcpy(n_labels, o + (size_t)n_utts * sizeof(float), (size_t)n_utts * sizeof(int32_t));
     memcpy(labels, o + (size_t)n_utts * (sizeof(float) + sizeof(int32_t)), (size_t)n_utts * label_cap);
     p->t_drain = pipe_now() - t4;
+    return LSR_OK;
+}
+
+extern "C" int lsr_host_check_finite(lsr_ctx* ctx, int flags) {
+    if (!ctx) return LSR_ERR_ARG;
+    if (flags < 0 || flags > 3) return lsr_fail(ctx, LSR_ERR_ARG, "lsr_host_check_finite: flags outside 0..3");
+    ctx->host_check_finite = flags;
     return LSR_OK;
 }
 
@@ -430,10 +469,19 @@ extern "C" int lsr_upload_host(lsr_ctx* ctx, const void* const* arrays, const in
             while (a < na && off[a0 + a] - base < goal) ++a;
             cut[t] = t == tasks ? na : a;
         }
+        const bool check = elem_bytes == 4 && (ctx->host_check_finite & 2);
+        std::atomic<int> bad_array(INT32_MAX);
         p->pool->parallel_for(tasks, [&](int t) {
             for (int i = a0 + cut[t]; i < a0 + cut[t + 1]; ++i)
-                if (n_elems[i]) copy_streaming(stage + (off[i] - base), arrays[i], (size_t)(off[i + 1] - off[i]));
+                if (n_elems[i] && !copy_streaming(stage + (off[i] - base), arrays[i], (size_t)(off[i + 1] - off[i]), check)) {
+                    int seen = bad_array.load();
+                    while (i < seen && !bad_array.compare_exchange_weak(seen, i)) {}
+                }
         });
+        if (bad_array.load() != INT32_MAX) {
+            if (last) LSR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, last, 0));      // copies already queued stay ordered
+            return lsr_fail(ctx, LSR_ERR_ARG, "lsr_upload_host: array %d holds a non-finite float32 value", bad_array.load());
+        }
         LSR_HIP_CHECK(ctx, hipMemcpyAsync((unsigned char*)dst_d + base, s.pinned, (size_t)bytes, hipMemcpyHostToDevice,
                                           p->copy_stream));
         LSR_HIP_CHECK(ctx, hipEventRecord(s.decoded, p->copy_stream));      // the slot is free again after its copy

@@ -65,6 +65,7 @@ def _declare(lib) -> None:
         "lsr_recognize_host_timing": (c_int, [P, POINTER(c_double), POINTER(c_int)]),
         "lsr_upload_host": (c_int, [P, P, P, c_int64, c_int, c_int64, c_int, P]),
         "lsr_download_host": (c_int, [P, P, c_int64, P, c_int64, c_int]),
+        "lsr_host_check_finite": (c_int, [P, c_int]),
         "lsr_shard_bounds": (None, [c_int64, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
         "lsr_comm_get_unique_id": (c_int, [P, P]),
         "lsr_comm_init": (c_int, [P, P, c_int, c_int]),
@@ -106,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "lsr_recognize_batch", "lsr_decode_chain_batch", "lsr_accumulate_stats", "lsr_remux_slots",
     "lsr_mfcc_batch_i16", "lsr_recognize_batch_i16", "lsr_model_set_mixtures", "lsr_separation_scan",
     "lsr_gather_segments", "lsr_decode_loop_sweep", "lsr_recognize_batch_noalloc",
-    "lsr_recognize_host", "lsr_recognize_host_timing", "lsr_upload_host", "lsr_download_host", "lsr_shard_bounds", "lsr_comm_get_unique_id", "lsr_comm_init",
+    "lsr_recognize_host", "lsr_recognize_host_timing", "lsr_upload_host", "lsr_download_host", "lsr_host_check_finite", "lsr_shard_bounds", "lsr_comm_get_unique_id", "lsr_comm_init",
     "lsr_comm_destroy", "lsr_allgather_labels", "lsr_allreduce_stats", "lsr_label_record_bytes",
     "lsr_host_pack_label_records", "lsr_host_unpack_label_records", "lsr_pack_label_records", "lsr_unpack_label_records",
     "lsr_labels_from_paths", "lsr_ll_stride", "lsr_decode_chain_batch_wide", "lsr_chain_emission_mode",
@@ -220,6 +221,16 @@ class Engine:
             msg = self.lib.lsr_last_error(self.ctx)
             raise NativeError(f"liblsr_hip error {rc}: {msg.decode() if msg else ''}")
 
+    def _check_audio(self, rc: int) -> None:
+        """_check for the calls that read host audio: a non-finite sample is the caller's ValueError (librosa's
+        valid_audio raises "Audio buffer is not finite everywhere" for the reference, mfcc.py:31)."""
+        if rc != 0:
+            msg = self.lib.lsr_last_error(self.ctx)
+            text = msg.decode() if msg else ""
+            if "non-finite" in text:
+                raise ValueError(f"Audio buffer is not finite everywhere ({text})")
+        self._check(rc)
+
     def close(self) -> None:
         if getattr(self, "ctx", None) is not None and self.ctx.value:
             self.lib.lsr_ctx_destroy(self.ctx)
@@ -264,10 +275,11 @@ class Engine:
     # -- batches ----------------------------------------------------------------------------------
     UPLOAD_PIPELINE_BYTES = 16 << 20      # lists of host arrays of at least this size go through lsr_upload_host
 
-    def _upload_list(self, arrays, ndim: int, inner: int):
+    def _upload_list(self, arrays, ndim: int, inner: int, audio: bool = False):
         """Device tensor holding the arrays of a list back to back, through the pinned / chunked upload pipeline,
         or None when the list does not qualify (small, mixed dtypes, non-contiguous): the caller then concatenates
-        on the host and copies once."""
+        on the host and copies once.  ``audio``: float32 arrays are checked for non-finite samples on the way
+        (ValueError, as librosa refuses such audio)."""
         if not isinstance(arrays, list) or len(arrays) == 0:
             return None
         first = arrays[0]
@@ -285,8 +297,12 @@ class Engine:
         if total * item < self.UPLOAD_PIPELINE_BYTES:
             return None
         out = self.empty((total,), dtype)
-        self._check(self.lib.lsr_upload_host(self.ctx, c_void_p(ptrs.ctypes.data), c_void_p(sizes.ctypes.data), len(arrays),
-                                             item, 0, 0, self._ptr(out)))
+        self._check(self.lib.lsr_host_check_finite(self.ctx, 3 if audio else 1))
+        try:
+            self._check_audio(self.lib.lsr_upload_host(self.ctx, c_void_p(ptrs.ctypes.data), c_void_p(sizes.ctypes.data),
+                                                       len(arrays), item, 0, 0, self._ptr(out)))
+        finally:
+            self.lib.lsr_host_check_finite(self.ctx, 1)
         return out
 
     def to_host(self, tensor) -> np.ndarray:
@@ -323,11 +339,15 @@ class Engine:
             raise ValueError(f"a clip yields {int(frames.min())} frames; the width-9 delta filter needs at least {MIN_FRAMES}")
         soff = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
         foff = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
-        audio = self._upload_list(signals, 1, 0)
+        audio = self._upload_list(signals, 1, 0, audio=True)
         if audio is None:
             # int16 PCM stays int16 (converted on the device); everything else is float32 like the reference's loader
             dtype = np.int16 if all(s.dtype == np.int16 for s in signals) else np.float32
-            audio = self.to_device(np.concatenate([np.asarray(s, dtype=dtype) for s in signals]))
+            flat = np.concatenate([np.asarray(s, dtype=dtype) for s in signals])
+            if dtype == np.float32 and not np.isfinite(flat).all():
+                bad = next(i for i, s in enumerate(signals) if not np.isfinite(np.asarray(s, dtype=np.float32)).all())
+                raise ValueError(f"Audio buffer is not finite everywhere (clip {bad})")
+            audio = self.to_device(flat)
         return AudioBatch(audio, self.to_device(soff), self.to_device(foff), n)
 
     def feature_batch(self, feats: Sequence[np.ndarray]) -> FeatureBatch:
@@ -536,10 +556,10 @@ class Engine:
         scores = np.empty(B, np.float32)
         labels = np.empty((B, label_cap), np.uint8)
         n_labels = np.empty(B, np.int32)
-        self._check(self.lib.lsr_recognize_host(self.ctx, c_void_p(ptrs.ctypes.data), c_void_p(n.ctypes.data), B,
-                                                1 if is_i16 else 0, int(chunk_samples), int(threads),
-                                                c_void_p(scores.ctypes.data), c_void_p(labels.ctypes.data),
-                                                c_void_p(n_labels.ctypes.data), label_cap))
+        self._check_audio(self.lib.lsr_recognize_host(self.ctx, c_void_p(ptrs.ctypes.data), c_void_p(n.ctypes.data), B,
+                                                      1 if is_i16 else 0, int(chunk_samples), int(threads),
+                                                      c_void_p(scores.ctypes.data), c_void_p(labels.ctypes.data),
+                                                      c_void_p(n_labels.ctypes.data), label_cap))
         return scores, labels, n_labels
 
     def recognize_host_timing(self) -> dict:

@@ -211,6 +211,14 @@ int lsr_recognize_host_timing(lsr_ctx* ctx, double* seconds4, int* n_chunks);
 int lsr_upload_host(lsr_ctx* ctx, const void* const* arrays, const int64_t* n_elems, int64_t n_arrays,
                     int elem_bytes, int64_t chunk_bytes, int n_threads, void* dst_d);
 
+/* Finiteness of host float32 data, tested while the packing threads copy it (no extra pass over memory).  librosa
+ * refuses audio that is not finite everywhere (librosa.util.valid_audio, reached from mfcc.py:31); the device front-end
+ * would turn such a clip into NaN features and an arbitrary string.  flags: bit 0 (default on) - float32 clips of
+ * lsr_recognize_host; bit 1 (default off) - the arrays of lsr_upload_host when elem_bytes is 4, for callers that
+ * upload float32 audio with it.  A non-finite value fails the call with LSR_ERR_ARG and the index of the lowest
+ * offending clip / array of the chunk in the message; chunks before it may already have been processed. */
+int lsr_host_check_finite(lsr_ctx* ctx, int flags);
+
 /* The other direction, for callers that want the features (or paths) back as host arrays, as MFCC.batch returns them
  * (mfcc.py:71-84): bytes of device memory to host memory through pinned staging chunks (0: 32 MiB) unpacked by
  * worker threads while the next chunk travels.  Ordered after the work queued on the context's stream; dst is

@@ -150,3 +150,53 @@ def test_download_equals_single_copy():
     feats = MFCC.batch(clips, 16000)                                # upload and download pipelines (24 MB of features)
     for i in (0, 17, 399):
         assert np.array_equal(feats[i], MFCC(clips[i], 16000).feature_vector.T)
+
+
+def test_non_finite_audio_is_refused_like_librosa_refuses_it(decoder):
+    """librosa.util.valid_audio (reached from mfcc.py:31) raises for audio that is not finite everywhere; every host
+    path into the device front-end does the same - the single copy of small lists, the chunked upload of large ones
+    and the streamed decoder, which test while they pack - and names the clip.  Feature arrays are not audio: a NaN
+    there is uploaded as it is.  The engine keeps working after a refusal."""
+    from loe_speech_recognition_amd import MFCC, _native, synthetic
+
+    eng = decoder._bind()
+    sigs, truth = synthetic.batch(3, 6, 2, start=4300)
+    for bad_value in (np.nan, np.inf, -np.inf):
+        broken = [s.copy() for s in sigs]
+        broken[4][1234] = bad_value
+        with pytest.raises(ValueError, match="not finite everywhere.*clip 4"):
+            MFCC.batch(broken, 16000)
+        with pytest.raises(ValueError, match="not finite everywhere"):
+            MFCC(broken[4], 16000)
+        with pytest.raises(ValueError, match="not finite everywhere.*clip 4"):
+            eng.recognize_host(broken, label_cap=8)
+        with pytest.raises(ValueError, match="not finite everywhere.*clip 4"):
+            eng.recognize_host(broken, label_cap=8, chunk_samples=1, threads=3)      # one clip per chunk
+    assert decoder.recognize_audio(sigs) == truth
+    # a list large enough for the chunked upload: the value sits in the unaligned head, the vector body or the tail of
+    # a clip's copy
+    rng = np.random.default_rng(11)
+    clips = [(rng.standard_normal(int(n)) * 3000).astype(np.float32) for n in rng.integers(20001, 60000, size=260)]
+    assert sum(c.nbytes for c in clips) >= eng.UPLOAD_PIPELINE_BYTES
+    for where in (0, 1, 2, 3, 4, 5000, -1, -2, -17):
+        broken = list(clips)
+        broken[77] = clips[77].copy()
+        broken[77][where] = np.nan
+        with pytest.raises(ValueError, match="not finite everywhere.*array 77"):
+            eng.audio_batch(broken)
+    ab = eng.audio_batch(clips)                                   # the same list without the value goes through
+    assert np.array_equal(ab.audio.cpu().numpy(), np.concatenate(clips))
+    feats = [rng.standard_normal((int(t), 39)).astype(np.float32) for t in rng.integers(100, 400, size=600)]
+    feats[5][7, 3] = np.nan
+    assert sum(f.nbytes for f in feats) >= eng.UPLOAD_PIPELINE_BYTES
+    assert np.isnan(eng.feature_batch(feats).feats[sum(f.shape[0] for f in feats[:5]) + 7, 3].item())
+    # the C setting: with bit 0 cleared the streamed decoder takes the clips as they are
+    import ctypes
+    broken = [s.copy() for s in sigs]
+    broken[2][10] = np.nan
+    assert eng.lib.lsr_host_check_finite(eng.ctx, 7) == -1
+    assert eng.lib.lsr_host_check_finite(eng.ctx, 0) == 0
+    try:
+        eng.recognize_host(broken, label_cap=8)
+    finally:
+        assert eng.lib.lsr_host_check_finite(eng.ctx, 1) == 0
