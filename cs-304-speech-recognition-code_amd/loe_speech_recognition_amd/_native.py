@@ -357,7 +357,8 @@ class Engine:
         if lengths.min() < 1:
             raise IndexError("index 0 is out of bounds for axis 0 with size 0")
         for f in feats:
-            assert f.ndim == 2 and f.shape[1] == DIM
+            if f.ndim != 2 or f.shape[1] != DIM:          # a real check: the kernels index rows of DIM floats
+                raise ValueError(f"feature arrays must have shape (T, {DIM}), got {f.shape}")
         foff = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
         flat = self._upload_list(feats, 2, DIM)
         if flat is not None and flat.dtype == self.torch.float32:
@@ -416,7 +417,9 @@ class Engine:
             whiten = cached
         log_norm = np.ascontiguousarray(log_norm, dtype=np.float64)
         S = mean.shape[0]
-        assert mean.shape == (S, DIM) and whiten.shape == (S, DIM, DIM) and log_norm.shape == (S,)
+        if mean.shape != (S, DIM) or whiten.shape != (S, DIM, DIM) or log_norm.shape != (S,):
+            raise ValueError(f"model arrays must have shapes ({S}, {DIM}), ({S}, {DIM}, {DIM}), ({S},): got "
+                             f"{mean.shape}, {whiten.shape}, {log_norm.shape}")
         if token is None:
             slot = 0
         else:
@@ -434,7 +437,8 @@ class Engine:
                                               log_norm.ctypes.data_as(dp)))
         if n_mix > 1:
             lw = np.ascontiguousarray(log_weights, dtype=np.float64)
-            assert lw.shape == (S,) and S % n_mix == 0
+            if lw.shape != (S,) or S % n_mix != 0:
+                raise ValueError(f"mixture weights must have shape ({S},) with {S} a multiple of n_mix = {n_mix}")
             self._check(self.lib.lsr_model_set_mixtures(self.ctx, n_mix, lw.ctypes.data_as(dp)))
         self._model_token = token
         self.n_model_states = S // n_mix
@@ -601,11 +605,13 @@ class Engine:
         if chain_state.shape != (total_chain,) or chain_state.min() < 0 or chain_state.max() >= self.n_model_states:
             raise ValueError("chain_state out of range of the uploaded model")
         chain_band = np.ascontiguousarray(chain_band, dtype=np.float32)
-        assert chain_band.shape == (3, total_chain)
+        if chain_band.shape != (3, total_chain):
+            raise ValueError(f"chain_band must have shape (3, {total_chain}), got {chain_band.shape}")
         if np.isnan(chain_band).any():
             raise ValueError("NaN transition log-probability")
         chain_start = np.ascontiguousarray(chain_start, dtype=np.uint8)
-        assert chain_start.shape == (total_chain,)
+        if chain_start.shape != (total_chain,):
+            raise ValueError(f"chain_start must have shape ({total_chain},), got {chain_start.shape}")
         d_off, d_state = self.to_device(chain_off), self.to_device(chain_state)
         d_band, d_start = self.to_device(chain_band), self.to_device(chain_start)
         self.last_chain = (d_off, d_state)           # device copies, reused by remux_slots
@@ -635,10 +641,13 @@ class Engine:
         between iterations: no host validation, no upload.  Returns (scores, paths), or (scores, paths, final)
         with ``want_final`` (last-frame scores of every chain position, chains of at most 64 states)."""
         t = self.torch
-        assert d_off.dtype == t.int64 and d_state.dtype == t.int32 and d_band.dtype == t.float32 and d_start.dtype == t.uint8
-        assert d_off.shape == (fb.n + 1,) and d_state.shape == (total_chain,) and d_band.shape == (3, total_chain)
-        assert d_start.shape == (total_chain,) and d_band.is_contiguous()
-        assert not (wide and want_final)
+        if not (d_off.dtype == t.int64 and d_state.dtype == t.int32 and d_band.dtype == t.float32 and d_start.dtype == t.uint8):
+            raise TypeError("chain description: offsets int64, states int32, band float32, start flags uint8")
+        if not (d_off.shape == (fb.n + 1,) and d_state.shape == (total_chain,) and d_band.shape == (3, total_chain)
+                and d_start.shape == (total_chain,) and d_band.is_contiguous()):
+            raise ValueError(f"chain description does not match {fb.n} utterances / {total_chain} chain positions")
+        if wide and want_final:
+            raise ValueError("the last-frame score table is only available for chains of at most 64 states")
         scores = self.empty((fb.n,), t.float32)
         paths = self.empty((fb.total_frames,), t.int8) if want_paths else None
         final = self.empty((fb.n, 64), t.float32) if want_final else None

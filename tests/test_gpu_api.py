@@ -124,6 +124,22 @@ def test_kernel_timing_can_be_limited_to_named_kernels(words):
         eng.profile_reset()
 
 
+def test_host_layer_checks_shapes_before_the_kernels_see_them(words):
+    """Shape mismatches are ValueErrors raised on the host (not asserts: the kernels index rows of 39 floats and trust
+    the sizes they are given)."""
+    from loe_speech_recognition_amd import _native
+
+    eng = _native.get_engine()
+    with pytest.raises(ValueError, match="shape"):
+        eng.feature_batch([np.zeros((10, 38), np.float32)])
+    with pytest.raises(ValueError, match="shape"):
+        eng.feature_batch([np.zeros((39,), np.float32)])
+    with pytest.raises(ValueError, match="model arrays"):
+        eng.set_model(_native.new_token(), np.zeros((3, 39)), np.zeros((3, 39, 38)), np.zeros(3))
+    with pytest.raises(ValueError, match="model arrays"):
+        eng.set_model(_native.new_token(), np.zeros((3, 39)), np.zeros((2, 39, 39)), np.zeros(3))
+
+
 def test_c_abi_rejects_bad_arguments():
     from loe_speech_recognition_amd import _native
 
