@@ -340,7 +340,7 @@ def main():
     inf._bind()
     names = inf._model_boundaries._labels
     comm = None
-    if world > 1 and args.comm == "capi":
+    if (world > 1 or args.exchange_at_one) and args.comm == "capi":
         from loe_speech_recognition_amd.distributed import NativeComm
         comm = NativeComm.from_torch_group(eng)
 
