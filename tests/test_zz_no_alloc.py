@@ -99,6 +99,41 @@ def test_noalloc_calls_on_two_streams_are_ordered():
         assert np.array_equal(ref[3].cpu().numpy(), got[3].cpu().numpy())
 
 
+def test_noalloc_at_both_limits_at_once():
+    """4 096 utterances of 16 frames: the most utterances and the most frames the static workspace takes, which is
+    also where the back-pointer groups (one partly filled group per utterance) need all of their part of it."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, synthetic
+
+    models = synthetic.load_word_models()
+    inf = HiddenMarkovModelInference.from_models([models[lab] for lab in synthetic.LOOP_ORDER])
+    inf._log_transition_probability_between_words = -100
+    eng = inf._bind()
+    lib = eng.lib
+    long, _ = synthetic.batch(3, 8, 2, start=1500)
+    rng = np.random.default_rng(3)
+    clips = []
+    for i in range(4096):                                  # 15 * 160 .. 15 * 160 + 159 samples: 16 frames each
+        src = np.asarray(long[i % len(long)], dtype=np.float32)
+        at = int(rng.integers(0, src.shape[0] - 2600))
+        clips.append(np.ascontiguousarray(src[at:at + 2400 + int(rng.integers(0, 160))]))
+    ab = eng.audio_batch(clips)
+    assert ab.n == 4096 and ab.total_frames == 65536 and ab.max_frames == 16
+    ref, got = _outputs(eng, ab), _outputs(eng, ab)
+    assert _call(eng, lib.lsr_recognize_batch, ab, ref) == 0
+    assert _call(eng, lib.lsr_recognize_batch_noalloc, ab, got) == 0, lib.lsr_last_error(eng.ctx)
+    assert np.array_equal(ref[0].cpu().numpy().view(np.uint8), got[0].cpu().numpy().view(np.uint8))
+    assert np.array_equal(ref[1].cpu().numpy(), got[1].cpu().numpy())
+    assert np.array_equal(ref[3].cpu().numpy(), got[3].cpu().numpy())
+    # the workspace is intact for the next, ordinary call
+    small, _ = synthetic.batch(2, 9, 1, start=60)
+    ab2 = eng.audio_batch([np.asarray(s, dtype=np.float32) for s in small])
+    ref2, got2 = _outputs(eng, ab2), _outputs(eng, ab2)
+    assert _call(eng, lib.lsr_recognize_batch, ab2, ref2) == 0
+    assert _call(eng, lib.lsr_recognize_batch_noalloc, ab2, got2) == 0
+    assert np.array_equal(ref2[1].cpu().numpy(), got2[1].cpu().numpy())
+    assert np.array_equal(ref2[0].cpu().numpy().view(np.uint8), got2[0].cpu().numpy().view(np.uint8))
+
+
 def test_noalloc_rejects_batches_beyond_the_static_workspace():
     from loe_speech_recognition_amd import HiddenMarkovModelInference, synthetic
 
