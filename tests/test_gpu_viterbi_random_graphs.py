@@ -190,6 +190,32 @@ def test_every_length_across_the_kernel_boundaries():
         assert np.array_equal(out[i][1], path), i
 
 
+def test_thousands_of_very_short_utterances():
+    """3 000 utterances of 2 .. 24 frames: nearly every back-pointer group is partly filled and every utterance
+    starts a group of its own, the shape in which the pointer table is largest relative to the frames."""
+    from loe_speech_recognition_amd import HiddenMarkovModelInference, _native
+
+    rng = np.random.default_rng(515)
+    words = _graph(rng, 50, tied=False)
+    inf = HiddenMarkovModelInference.from_models([trainable(*w) for w in words])
+    inf._log_transition_probability_between_words = -4
+    ltp, gauss, bounds = O.stack_models([O.WordModelRef(*w) for w in words])
+    S = bounds.num_states
+    band = O.band_from_ltp(ltp, S, [bounds.find_lower(s) for s in range(S)])
+    xs = [(1.5 * rng.standard_normal((int(t), 39))).astype(np.float32) for t in rng.integers(2, 25, size=3000)]
+    vit = inf.viterbi_batch(xs)
+    strings = inf.predict_batch(xs)
+    eng = _native.get_engine()
+    inf._bind()
+    ll = eng.emission(eng.feature_batch(xs)).cpu().numpy()
+    t0 = 0
+    for i, x in enumerate(xs):
+        score, path = O.viterbi_loop_fast(ll[t0:t0 + x.shape[0], :S], band, bounds.lower, bounds.upper, -4)
+        t0 += x.shape[0]
+        assert vit[i][0] == score and np.array_equal(vit[i][1], path), i
+        assert strings[i] == "".join(bounds.get_labels(path)), i
+
+
 def test_utterance_longer_than_64k_frames_and_the_limit():
     """One utterance of 70 000 frames (its path needs more than 64 KiB of LDS, a size the launcher has to ask for)
     next to a short one; beyond the LDS of a compute unit the decoder refuses with a clear error."""
